@@ -1,0 +1,494 @@
+"""
+oracle.py -- NumPy (float64) restatement of the reference's super-resolution hot
+path, plus a ctypes binding of the C restatement (srx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module, and only as the checker / the CPU figure.
+The product package (ml_super_resolution_amd) never imports it.
+
+PARITY STATUS: "parity unpinned" for conv / backward / optimizer arithmetic: the
+reference (imironhead/ml_super_resolution) delegates those to TensorFlow 1.8, which
+is absent from /root/reference and not installable here, and the reference holds no
+tests or golden vectors.  Pinned by reference data / code:
+  P1  the sub-pixel index map: three independent reference spellings restated
+      verbatim-in-behaviour below (`*_ref_spelling_*`) must agree with the closed
+      form used everywhere else;
+  P2  conv.N taps are post-ReLU (assets vdsr-fig2-conv.N == vdsr-fig2-relu.N);
+  P3  residual add + truncating uint8 encode (assets vdsr-fig2-{sd,conv.20,sr});
+  P4  SRCNN VALID geometry 243 -> 231.
+All citations are relative to /root/reference.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+_ACT_BY_NAME = {None: ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH,
+                'lrelu': ACT_LRELU, 'sigmoid': ACT_SIGMOID}
+
+
+# ----------------------------------------------------------------------------
+# geometry helpers (TF-1.8 padding semantics, stride 1)
+# ----------------------------------------------------------------------------
+def same_pad(k):
+    """TF 'SAME', stride 1: pad_total = k-1, pad_before = pad_total // 2."""
+    return (k - 1) // 2
+
+
+def conv_geometry(H, W, KH, KW, padding):
+    """-> (pad_t, pad_l, OH, OW) for stride-1 SAME / VALID."""
+    if padding.upper() == 'SAME':
+        return same_pad(KH), same_pad(KW), H, W
+    if padding.upper() == 'VALID':
+        return 0, 0, H - KH + 1, W - KW + 1
+    raise ValueError(padding)
+
+
+def srcnn_sanity_check(crop_image_size=256, fsub=33, f1=9, f2=1, f3=5):
+    """srcnn/srcnn.py:28-40 (Python-2 integer division)."""
+    smaller = fsub - f1 - f2 - f3 + 3
+    boundary = (fsub - smaller) // 2
+    crop = (crop_image_size - boundary * 2) // smaller
+    return boundary, crop * smaller + boundary * 2   # (crop_image_side, crop_image_size)
+
+
+# ----------------------------------------------------------------------------
+# activations
+# ----------------------------------------------------------------------------
+def act_apply(v, act):
+    act = _ACT_BY_NAME.get(act, act)
+    if act == ACT_RELU:
+        return np.maximum(v, 0.0)
+    if act == ACT_TANH:
+        return np.tanh(v)
+    if act == ACT_LRELU:
+        return np.where(v > 0, v, 0.2 * v)
+    if act == ACT_SIGMOID:
+        return 1.0 / (1.0 + np.exp(-v))
+    return v
+
+
+def act_grad_from_y(y, act):
+    act = _ACT_BY_NAME.get(act, act)
+    if act == ACT_RELU:
+        return (y > 0).astype(y.dtype)
+    if act == ACT_TANH:
+        return 1.0 - y * y
+    if act == ACT_LRELU:
+        return np.where(y > 0, 1.0, 0.2).astype(y.dtype)
+    if act == ACT_SIGMOID:
+        return y * (1.0 - y)
+    return np.ones_like(y)
+
+
+# ----------------------------------------------------------------------------
+# convolution (float64 NumPy)
+# ----------------------------------------------------------------------------
+def _pad_input(x, KH, KW, pad_t, pad_l, OH, OW):
+    N, H, W, C = x.shape
+    pad_b = max(OH + KH - 1 - pad_t - H, 0)
+    pad_r = max(OW + KW - 1 - pad_l - W, 0)
+    return np.pad(x, ((0, 0), (pad_t, pad_b), (pad_l, pad_r), (0, 0)))
+
+
+def conv2d_fwd(x, w, b=None, padding='SAME', act=None, skip=None, post_relu=False,
+               dtype=np.float64):
+    """y = act(b + x (*) w) [+ skip] [relu].  NHWC x, HWIO w, cross-correlation.
+    vdsr/vdsr/model_vdsr.py:62-76,85-104; espcn/espcn/model_espcn.py:117-134."""
+    x = np.asarray(x, dtype)
+    w = np.asarray(w, dtype)
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = w.shape
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    xp = _pad_input(x, KH, KW, pad_t, pad_l, OH, OW)
+    y = np.zeros((N, OH, OW, Cout), dtype)
+    for kh in range(KH):
+        for kw in range(KW):
+            y += xp[:, kh:kh + OH, kw:kw + OW, :] @ w[kh, kw]
+    if b is not None:
+        y = y + np.asarray(b, dtype)
+    y = act_apply(y, act)
+    if skip is not None:
+        y = y + np.asarray(skip, dtype)
+    if post_relu:
+        y = np.maximum(y, 0.0)
+    return y
+
+
+def conv2d_bwd_data(dpre, w, in_hw, padding='SAME', dtype=np.float64):
+    """dx[n,h,w,ci] = sum dpre[n,h+pad_t-kh,w+pad_l-kw,co] w[kh,kw,ci,co]."""
+    dpre = np.asarray(dpre, dtype)
+    w = np.asarray(w, dtype)
+    H, W = in_hw
+    KH, KW, Cin, Cout = w.shape
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    N = dpre.shape[0]
+    dxp = np.zeros((N, OH + KH - 1, OW + KW - 1, Cin), dtype)
+    for kh in range(KH):
+        for kw in range(KW):
+            dxp[:, kh:kh + OH, kw:kw + OW, :] += dpre @ w[kh, kw].T
+    return dxp[:, pad_t:pad_t + H, pad_l:pad_l + W, :]
+
+
+def conv2d_bwd_filter(x, dpre, ksize, padding='SAME', dtype=np.float64):
+    """dw[kh,kw,ci,co] = sum x[n,oh+kh-pad_t,ow+kw-pad_l,ci] dpre[n,oh,ow,co]; db = sum dpre."""
+    x = np.asarray(x, dtype)
+    dpre = np.asarray(dpre, dtype)
+    KH, KW = ksize
+    N, H, W, Cin = x.shape
+    Cout = dpre.shape[-1]
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    xp = _pad_input(x, KH, KW, pad_t, pad_l, OH, OW)
+    dw = np.zeros((KH, KW, Cin, Cout), dtype)
+    d2 = dpre.reshape(-1, Cout)
+    for kh in range(KH):
+        for kw in range(KW):
+            dw[kh, kw] = xp[:, kh:kh + OH, kw:kw + OW, :].reshape(-1, Cin).T @ d2
+    return dw, d2.sum(axis=0)
+
+
+# ----------------------------------------------------------------------------
+# sub-pixel index map (pin P1)
+# ----------------------------------------------------------------------------
+def depth_to_space(x, r):
+    """Closed form: out[n,h*r+dy,w*r+dx,c] = in[n,h,w,(dy*r+dx)*C+c]."""
+    N, H, W, D = x.shape
+    C = D // (r * r)
+    return x.reshape(N, H, W, r, r, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H * r, W * r, C)
+
+
+def space_to_depth(x, r):
+    """Inverse of depth_to_space."""
+    N, HR, WR, C = x.shape
+    H, W = HR // r, WR // r
+    return x.reshape(N, H, r, W, r, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H, W, r * r * C)
+
+
+def d2s_ref_spelling_test(sr_result, sf):
+    """Behavioural restatement of espcn/espcn/experiment_test.py:171-177 for one
+    image [lrh, lrw, 3*sf*sf]: split along width, reshape, concatenate."""
+    lrh, lrw, _ = sr_result.shape
+    patches = np.split(sr_result, lrw, axis=1)
+    patches = [np.reshape(p, [lrh * sf, sf, 3]) for p in patches]
+    return np.concatenate(patches, axis=1)
+
+
+def d2s_ref_spelling_train(batch, lr_patch_size, sf):
+    """Behavioural restatement of espcn/espcn/experiment_train.py:49-56 for a batch
+    [B, P, P, 3*sf*sf] -> [1, B*P*sf, P*sf, 3] (one tall strip, as the summary does)."""
+    B = batch.shape[0]
+    shape = [1, B * lr_patch_size * sf, sf, 3]
+    subs = np.split(batch, lr_patch_size, axis=2)
+    subs = [np.reshape(s, shape) for s in subs]
+    return np.concatenate(subs, axis=2)
+
+
+def s2d_ref_spelling_dataset(hr_patch, lr_patch_size):
+    """Behavioural restatement of espcn/espcn/dataset.py:140-156 (and
+    experiment_test.py:91-96) for one HR patch [P*r, P*r, C]."""
+    subs = np.split(hr_patch, lr_patch_size, axis=1)
+    subs = [s.reshape([lr_patch_size, 1, -1]) for s in subs]
+    return np.concatenate(subs, axis=1)
+
+
+# ----------------------------------------------------------------------------
+# losses / optimizers / metrics
+# ----------------------------------------------------------------------------
+def mse_fwd_bwd(pred, target, numel_global=None):
+    """tf.losses.mean_squared_error(reduction=MEAN); vdsr/vdsr/model_vdsr.py:120-123."""
+    pred = np.asarray(pred, np.float64)
+    target = np.asarray(target, np.float64)
+    n = pred.size if numel_global is None else numel_global
+    d = pred - target
+    return float((d * d).sum() / n), 2.0 * d / n
+
+
+def l2_loss(w):
+    """tf.nn.l2_loss = sum(w^2)/2; model_vdsr.py:34 multiplies by 1e-4."""
+    w = np.asarray(w, np.float64)
+    return 0.5 * float((w * w).sum())
+
+
+def adam_tf(w, g, m, v, lr, t, b1=0.9, b2=0.999, eps=1e-8):
+    """TF-1.x Adam (epsilon-hat).  t = 1-based step.  Returns (w, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    w = w - lr_t * m / (np.sqrt(v) + eps)
+    return w, m, v
+
+
+def momentum_clip(w, g, acc, lr, mom=0.9, gradient_cap=0.01):
+    """vdsr/vdsr/model_vdsr.py:158-184: clip to +-(cap/lr) then TF Momentum."""
+    cap = gradient_cap / lr
+    g = np.clip(g, -cap, cap)
+    acc = mom * acc + g
+    return w - lr * acc, acc
+
+
+def psnr(a, b, max_val):
+    """tf.image.psnr per image; vdsr/vdsr/experiment_train.py:80-82."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(axis=1)
+    return 20.0 * np.log10(max_val) - 10.0 * np.log10(mse)
+
+
+def saturate_u8(x):
+    """tf.saturate_cast(x*127.5+127.5, uint8): clamp then truncate.
+    vdsr/vdsr/experiment_resolve.py:65-69."""
+    v = np.asarray(x, np.float32) * np.float32(127.5) + np.float32(127.5)
+    return np.clip(v, 0.0, 255.0).astype(np.uint8)
+
+
+def lr_schedule(lr0, factor, step, decay_steps):
+    """vdsr/vdsr/experiment_train.py:130; espcn/espcn/experiment_train.py:101-107."""
+    return lr0 * (factor ** (step // decay_steps))
+
+
+# ----------------------------------------------------------------------------
+# whole networks
+# ----------------------------------------------------------------------------
+def vdsr_param_shapes(num_layers=20, channels=3, width=64):
+    shapes = []
+    cin = channels
+    for i in range(num_layers - 1):
+        shapes.append(((3, 3, cin, width), (width,)))
+        cin = width
+    shapes.append(((3, 3, cin, channels), (channels,)))
+    return shapes
+
+
+def xavier_uniform(rng, shape):
+    """tf.contrib.layers.xavier_initializer(): U(+-sqrt(6/(fan_in+fan_out))),
+    fan = kh*kw*C.  (TF's RNG stream itself is not reproducible: tests inject weights.)"""
+    kh, kw, cin, cout = shape
+    lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def truncated_normal(rng, shape, stddev):
+    """tf.truncated_normal_initializer: redraw beyond 2 sigma."""
+    out = rng.normal(0.0, stddev, size=shape)
+    bad = np.abs(out) > 2 * stddev
+    while bad.any():
+        out[bad] = rng.normal(0.0, stddev, size=int(bad.sum()))
+        bad = np.abs(out) > 2 * stddev
+    return out.astype(np.float32)
+
+
+def vdsr_forward(sd, params, dtype=np.float64):
+    """vdsr/vdsr/model_vdsr.py:47-106.  params = [(kernel, bias)] * num_layers.
+    Returns dict with conv.i / relu.i (same post-ReLU tensor), conv.N, sr_images."""
+    out = {'sd_images': np.asarray(sd, dtype)}
+    t = out['sd_images']
+    n = len(params)
+    for i, (k, b) in enumerate(params[:-1]):
+        t = conv2d_fwd(t, k, b, 'SAME', 'relu', dtype=dtype)
+        out['conv.%d' % (i + 1)] = t
+        out['relu.%d' % (i + 1)] = t          # second relu is idempotent (:74)
+    k, b = params[-1]
+    res = conv2d_fwd(t, k, b, 'SAME', None, dtype=dtype)
+    out['conv.%d' % n] = res
+    out['sr_images'] = out['sd_images'] + res
+    return out
+
+
+def vdsr_loss_and_grads(sd, hd, params, weight_decay=1e-4, numel_global=None, dtype=np.float64):
+    """Forward + TF-autodiff-equivalent backward of model_vdsr.py:120-125.
+    Returns (loss, [(dk, db)], fwd dict).  With numel_global set (data-parallel
+    shard) the regulariser gradient is NOT added (caller adds it once after the
+    reduce) -- see grads_add_l2."""
+    fwd = vdsr_forward(sd, params, dtype)
+    mse, d_sr = mse_fwd_bwd(fwd['sr_images'], hd, numel_global)
+    reg = sum(weight_decay * l2_loss(k) for k, _ in params)
+    n = len(params)
+    grads = [None] * n
+    acts = [fwd['sd_images']] + [fwd['conv.%d' % (i + 1)] for i in range(n - 1)]
+    dpre = d_sr                                        # last layer has no activation
+    for i in range(n - 1, -1, -1):
+        k, _ = params[i]
+        dk, db = conv2d_bwd_filter(acts[i], dpre, k.shape[:2], 'SAME', dtype)
+        grads[i] = (dk, db)
+        if i > 0:
+            dx = conv2d_bwd_data(dpre, k, acts[i].shape[1:3], 'SAME', dtype)
+            dpre = dx * act_grad_from_y(acts[i], 'relu')
+    if numel_global is None:
+        grads = [(dk + weight_decay * np.asarray(k, dtype), db) for (dk, db), (k, _) in zip(grads, params)]
+    return mse + reg, grads, fwd
+
+
+def espcn_forward(lr, params, dtype=np.float64):
+    """espcn/espcn/model_espcn.py:30-62 / :117-134: tanh, tanh, linear; all SAME."""
+    (k1, b1), (k2, b2), (k3, b3) = params
+    t = conv2d_fwd(lr, k1, b1, 'SAME', 'tanh', dtype=dtype)
+    t = conv2d_fwd(t, k2, b2, 'SAME', 'tanh', dtype=dtype)
+    return conv2d_fwd(t, k3, b3, 'SAME', None, dtype=dtype)
+
+
+def espcn_scaling_factor(f3_bias):
+    """espcn/espcn/model_espcn.py:108."""
+    return int((np.asarray(f3_bias).size // 3) ** 0.5)
+
+
+def srcnn_forward(lo, params, dtype=np.float64):
+    """srcnn/srcnn.py:100-130: relu, relu, tanh; all VALID."""
+    (k1, b1), (k2, b2), (k3, b3) = params
+    t = conv2d_fwd(lo, k1, b1, 'VALID', 'relu', dtype=dtype)
+    t = conv2d_fwd(t, k2, b2, 'VALID', 'relu', dtype=dtype)
+    return conv2d_fwd(t, k3, b3, 'VALID', 'tanh', dtype=dtype)
+
+
+def srcnn_loss(sr, hi):
+    """srcnn/srcnn.py:142-144: mean over rows of the L2 norm of reshape(diff,[-1,bb^2])."""
+    sr = np.asarray(sr, np.float64)
+    bb = sr.shape[1]
+    d = (sr - np.asarray(hi, np.float64)).reshape(-1, bb * bb)
+    return float(np.sqrt((d * d).sum(axis=1)).mean())
+
+
+# ----------------------------------------------------------------------------
+# C restatement (srx_oracle.c) via ctypes -- used for larger cases and as the
+# cpu_baseline "port"
+# ----------------------------------------------------------------------------
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_clib = None
+
+
+def clib():
+    global _clib
+    if _clib is None:
+        path = os.path.join(_HERE, 'libsrx_oracle.so')
+        if not os.path.exists(path):
+            raise RuntimeError('oracle C library not built: run `make -C oracle` '
+                               '(or __graft_entry__.build())')
+        L = ctypes.CDLL(path)
+        fp = ctypes.POINTER(ctypes.c_float)
+        i = ctypes.c_int
+        L.srx_ref_conv2d_fwd.argtypes = [fp, fp, fp, fp, fp] + [i] * 13
+        L.srx_ref_conv2d_fwd.restype = None
+        L.srx_ref_act_bwd.argtypes = [fp, fp, fp, ctypes.c_size_t, i]
+        L.srx_ref_conv2d_bwd_data.argtypes = [fp, fp, fp] + [i] * 11
+        L.srx_ref_conv2d_bwd_filter.argtypes = [fp, fp, fp, fp] + [i] * 11
+        L.srx_ref_depth_to_space.argtypes = [fp, fp] + [i] * 5
+        L.srx_ref_space_to_depth.argtypes = [fp, fp] + [i] * 5
+        L.srx_ref_mse_fwd_bwd.argtypes = [fp, fp, fp, ctypes.c_size_t, ctypes.c_double]
+        L.srx_ref_mse_fwd_bwd.restype = ctypes.c_double
+        L.srx_ref_l2_loss.argtypes = [fp, ctypes.c_size_t]
+        L.srx_ref_l2_loss.restype = ctypes.c_double
+        L.srx_ref_adam_tf.argtypes = [fp, fp, fp, fp, ctypes.c_size_t] + [ctypes.c_float] * 4 + [ctypes.c_long]
+        L.srx_ref_momentum_clip.argtypes = [fp, fp, fp, ctypes.c_size_t] + [ctypes.c_float] * 3
+        L.srx_ref_psnr.argtypes = [fp, fp, fp, i, ctypes.c_size_t, ctypes.c_float]
+        L.srx_ref_saturate_u8.argtypes = [fp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t]
+        L.srx_ref_num_threads.restype = i
+        _clib = L
+    return _clib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def c_conv2d_fwd(x, w, b=None, padding='SAME', act=None, skip=None, post_relu=False):
+    x, w = _f32(x), _f32(w)
+    b = None if b is None else _f32(b)
+    skip = None if skip is None else _f32(skip)
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = w.shape
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    y = np.empty((N, OH, OW, Cout), np.float32)
+    clib().srx_ref_conv2d_fwd(_p(x), _p(w), _p(b), _p(skip), _p(y), N, H, W, Cin, Cout, KH, KW,
+                              pad_t, pad_l, OH, OW, _ACT_BY_NAME.get(act, act), int(post_relu))
+    return y
+
+
+def c_act_bwd(dy, y, act):
+    dy, y = _f32(dy), _f32(y)
+    out = np.empty_like(dy)
+    clib().srx_ref_act_bwd(_p(dy), _p(y), _p(out), dy.size, _ACT_BY_NAME.get(act, act))
+    return out
+
+
+def c_conv2d_bwd_data(dpre, w, in_hw, padding='SAME'):
+    dpre, w = _f32(dpre), _f32(w)
+    H, W = in_hw
+    KH, KW, Cin, Cout = w.shape
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    N = dpre.shape[0]
+    dx = np.empty((N, H, W, Cin), np.float32)
+    clib().srx_ref_conv2d_bwd_data(_p(dpre), _p(w), _p(dx), N, H, W, Cin, Cout, KH, KW,
+                                   pad_t, pad_l, OH, OW)
+    return dx
+
+
+def c_conv2d_bwd_filter(x, dpre, ksize, padding='SAME'):
+    x, dpre = _f32(x), _f32(dpre)
+    KH, KW = ksize
+    N, H, W, Cin = x.shape
+    Cout = dpre.shape[-1]
+    pad_t, pad_l, OH, OW = conv_geometry(H, W, KH, KW, padding)
+    dw = np.empty((KH, KW, Cin, Cout), np.float32)
+    db = np.empty((Cout,), np.float32)
+    clib().srx_ref_conv2d_bwd_filter(_p(x), _p(dpre), _p(dw), _p(db), N, H, W, Cin, Cout, KH, KW,
+                                     pad_t, pad_l, OH, OW)
+    return dw, db
+
+
+def c_depth_to_space(x, r):
+    x = _f32(x)
+    N, H, W, D = x.shape
+    C = D // (r * r)
+    out = np.empty((N, H * r, W * r, C), np.float32)
+    clib().srx_ref_depth_to_space(_p(x), _p(out), N, H, W, C, r)
+    return out
+
+
+def c_space_to_depth(x, r):
+    x = _f32(x)
+    N, HR, WR, C = x.shape
+    H, W = HR // r, WR // r
+    out = np.empty((N, H, W, C * r * r), np.float32)
+    clib().srx_ref_space_to_depth(_p(x), _p(out), N, H, W, C, r)
+    return out
+
+
+def c_adam_tf(w, g, m, v, lr, t, b1=0.9, b2=0.999, eps=1e-8):
+    w, g, m, v = _f32(w).copy(), _f32(g), _f32(m).copy(), _f32(v).copy()
+    clib().srx_ref_adam_tf(_p(w), _p(g), _p(m), _p(v), w.size, lr, b1, b2, eps, int(t))
+    return w, m, v
+
+
+def c_vdsr_forward(sd, params):
+    """C-oracle VDSR forward (fp32), used for the cpu_baseline timing."""
+    t = _f32(sd)
+    for k, b in params[:-1]:
+        t = c_conv2d_fwd(t, k, b, 'SAME', 'relu')
+    k, b = params[-1]
+    return c_conv2d_fwd(t, k, b, 'SAME', None, skip=_f32(sd))
+
+
+def c_vdsr_train_step_grads(sd, hd, params, weight_decay=1e-4):
+    """C-oracle forward + backward (fp32); returns (loss, grads)."""
+    acts = [_f32(sd)]
+    for k, b in params[:-1]:
+        acts.append(c_conv2d_fwd(acts[-1], k, b, 'SAME', 'relu'))
+    k, b = params[-1]
+    sr = c_conv2d_fwd(acts[-1], k, b, 'SAME', None, skip=acts[0])
+    hd = _f32(hd)
+    dpre = np.empty_like(sr)
+    mse = clib().srx_ref_mse_fwd_bwd(_p(sr), _p(hd), _p(dpre), sr.size, float(sr.size))
+    reg = sum(weight_decay * clib().srx_ref_l2_loss(_p(_f32(k)), k.size) for k, _ in params)
+    grads = [None] * len(params)
+    for i in range(len(params) - 1, -1, -1):
+        k, _ = params[i]
+        dk, db = c_conv2d_bwd_filter(acts[i], dpre, k.shape[:2], 'SAME')
+        grads[i] = (dk + np.float32(weight_decay) * _f32(k), db)
+        if i > 0:
+            dx = c_conv2d_bwd_data(dpre, k, acts[i].shape[1:3], 'SAME')
+            dpre = c_act_bwd(dx, acts[i], 'relu')
+    return mse + reg, grads

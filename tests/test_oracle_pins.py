@@ -1,0 +1,87 @@
+"""Weight-independent pins the reference does hold."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import GOLDEN
+
+
+@pytest.mark.parametrize('r', [2, 3, 4])
+def test_p1_three_reference_spellings_agree(r, golden_d2s):
+    """espcn/espcn/experiment_test.py:171-177, experiment_train.py:47-56,
+    dataset.py:140-156 / experiment_test.py:91-96 all describe ONE index map."""
+    rng = np.random.default_rng(r)
+    B, P = 3, 5
+    x = rng.integers(0, 1 << 20, size=(B, P, P, 3 * r * r)).astype(np.int64)
+    closed = O.depth_to_space(x, r)
+    for n in range(B):
+        np.testing.assert_array_equal(O.d2s_ref_spelling_test(x[n], r), closed[n])
+    strip = O.d2s_ref_spelling_train(x, P, r)                # [1, B*P*r, P*r, 3]
+    np.testing.assert_array_equal(strip[0], closed.reshape(B * P * r, P * r, 3))
+    for n in range(B):
+        np.testing.assert_array_equal(O.s2d_ref_spelling_dataset(closed[n], P), x[n])
+    np.testing.assert_array_equal(O.space_to_depth(closed, r), x)
+    # non-square, via the C restatement as well
+    y = rng.normal(size=(2, 4, 7, 3 * r * r)).astype(np.float32)
+    np.testing.assert_array_equal(O.c_depth_to_space(y, r), O.depth_to_space(y, r))
+    np.testing.assert_array_equal(O.c_space_to_depth(O.depth_to_space(y, r), r), y)
+    # closed form out[n,h*r+dy,w*r+dx,c] = in[n,h,w,(dy*r+dx)*C+c]
+    d = O.depth_to_space(y, r)
+    for (n, h, w, dy, dx, c) in [(0, 0, 0, 0, 0, 0), (1, 3, 6, r - 1, r - 1, 2), (1, 2, 5, r - 1, 0, 1)]:
+        assert d[n, h * r + dy, w * r + dx, c] == y[n, h, w, (dy * r + dx) * 3 + c]
+    # committed exhaustive integer maps
+    N, H, W, C = 2, 5, 7, 3
+    src = np.arange(N * H * W * C * r * r, dtype=np.int64).reshape(N, H, W, C * r * r)
+    np.testing.assert_array_equal(O.depth_to_space(src, r), golden_d2s['r%d.d2s' % r])
+    hr = np.arange(N * H * r * W * r * C, dtype=np.int64).reshape(N, H * r, W * r, C)
+    np.testing.assert_array_equal(O.space_to_depth(hr, r), golden_d2s['r%d.s2d' % r])
+
+
+def test_p1_not_torch_pixel_shuffle_order():
+    """TF depth_to_space is (dy,dx,c) with c fastest; torch.pixel_shuffle is (c,dy,dx)."""
+    import torch
+    r, C = 3, 3
+    x = np.arange(1 * 2 * 2 * C * r * r, dtype=np.float32).reshape(1, 2, 2, C * r * r)
+    ours = O.depth_to_space(x, r)
+    ps = torch.pixel_shuffle(torch.from_numpy(x).permute(0, 3, 1, 2), r).permute(0, 2, 3, 1).numpy()
+    assert not np.array_equal(ours, ps)
+    perm = x.reshape(1, 2, 2, r, r, C).transpose(0, 1, 2, 5, 3, 4).reshape(1, 2, 2, C * r * r)
+    ps2 = torch.pixel_shuffle(torch.from_numpy(perm).permute(0, 3, 1, 2), r).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_array_equal(ours, ps2)
+
+
+def test_p2_conv_taps_are_post_relu():
+    """assets/vdsr-fig2-conv.N.png are byte-identical to vdsr-fig2-relu.N.png and
+    never darker than 127 (= 0.0): the tap named conv.N is post-ReLU."""
+    pins = json.load(open(os.path.join(GOLDEN, 'pins.json')))
+    for n in ('1', '5', '19'):
+        assert pins['P2'][n]['conv_sha256'] == pins['P2'][n]['relu_sha256']
+        assert pins['P2'][n]['min_pixel'] >= 127
+    assert int(O.saturate_u8(np.array([0.0]))[0]) == 127
+
+
+def test_p3_residual_add_and_truncating_encode():
+    """sr = sd + conv.20, each encoded with saturate_cast(x*127.5+127.5):
+    sr_u8 ~= sd_u8 + conv20_u8 - 127.5 up to the three truncations."""
+    z = np.load(os.path.join(GOLDEN, 'pin_p3_crop.npz'))
+    sd = z['sd_image'].astype(np.float64); res = z['conv_20'].astype(np.float64); sr = z['sr_image'].astype(np.float64)
+    pred = sd + res - 127.5
+    ok = (pred > 1) & (pred < 254)
+    assert ok.mean() > 0.95
+    assert np.abs(pred - sr)[ok].max() <= 1.5
+    # and the restated pipeline obeys the same bound on synthetic floats
+    rng = np.random.default_rng(0)
+    sdf = rng.uniform(-0.9, 0.9, 1000); rf = rng.uniform(-0.05, 0.05, 1000)
+    p = O.saturate_u8(sdf).astype(float) + O.saturate_u8(rf).astype(float) - 127.5
+    assert np.abs(p - O.saturate_u8(sdf + rf)).max() <= 1.5
+
+
+def test_p4_srcnn_panel_geometry():
+    """assets/srcnn_000.jpg is hd|sd|sr of 231x231 (srcnn/srcnn.py:169-184)."""
+    pins = json.load(open(os.path.join(GOLDEN, 'pins.json')))
+    side, size = O.srcnn_sanity_check(256)
+    out = size - (9 - 1) - (1 - 1) - (5 - 1)
+    assert pins['P4'] == {'width': 3 * out, 'height': out}
