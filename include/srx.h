@@ -1,0 +1,174 @@
+/*
+ * srx.h -- C ABI of libsrx.so, the MI355X (gfx950) super-resolution conv engine.
+ *
+ * The reference (imironhead/ml_super_resolution) has no FFI / plugin boundary: its
+ * hot path is reached through TensorFlow-1.8's Python op API.  Each entry point below
+ * names the reference call site(s) whose TF op it replaces (paths relative to
+ * /root/reference).  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (e.g. a PyTorch-ROCm
+ *     tensor's data_ptr()); fp32; activations NHWC, filters HWIO [KH,KW,Cin,Cout];
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); the
+ *     library never synchronises the device and allocates nothing per call;
+ *   - returns SRX_OK (0) or a negative srx_status; srx_last_error() gives the text
+ *     (thread-local); bad shapes / alignment are errors, never undefined behaviour;
+ *   - base pointers of activations / filters must be 16-byte aligned.
+ */
+#ifndef SRX_H_
+#define SRX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* srx_stream_t; /* hipStream_t */
+
+typedef enum {
+    SRX_OK = 0,
+    SRX_ERR_BAD_ARG = -1,     /* null pointer, non-positive dim, unknown enum */
+    SRX_ERR_UNSUPPORTED = -2, /* shape outside the compiled kernel set (e.g. stride != 1) */
+    SRX_ERR_WORKSPACE = -3,   /* workspace missing or too small */
+    SRX_ERR_LAUNCH = -4,      /* HIP runtime reported an error at launch */
+    SRX_ERR_ALIGN = -5        /* pointer not 16-byte aligned */
+} srx_status;
+
+typedef enum { SRX_PAD_SAME = 0, SRX_PAD_VALID = 1 } srx_pad_mode;
+
+typedef enum {
+    SRX_ACT_NONE = 0,
+    SRX_ACT_RELU = 1,   /* vdsr/vdsr/model_vdsr.py:68, srcnn/srcnn.py:106,117 */
+    SRX_ACT_TANH = 2,   /* espcn/espcn/model_espcn.py:36,46,120,126; srcnn/srcnn.py:128 */
+    SRX_ACT_LRELU = 3,  /* leaky_relu(0.2): enet/enet/model_enet.py:130-146 */
+    SRX_ACT_SIGMOID = 4 /* enet/enet/model_enet.py:160 */
+} srx_act;
+
+typedef enum { SRX_OP_FWD = 0, SRX_OP_BWD_DATA = 1, SRX_OP_BWD_FILTER = 2 } srx_conv_op;
+
+/* One stride-1 convolution layer.  N,H,W,Cin describe the layer INPUT x; the output
+ * is [N,OH,OW,Cout] with OH,OW from pad_mode (TF semantics: SAME -> OH=H, pad_before =
+ * (K-1)/2; VALID -> OH = H-KH+1). */
+typedef struct {
+    int32_t N, H, W, Cin, Cout, KH, KW;
+    int32_t stride;        /* must be 1 (ENet's stride-2 discriminator is out of scope) */
+    int32_t pad_mode;      /* srx_pad_mode */
+    int32_t act;           /* srx_act fused after bias */
+    int32_t post_add_relu; /* relu after the skip add: enet/enet/model_enet.py:8-31 */
+    int32_t precision;     /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32); the only mode */
+} srx_conv_desc;
+
+const char* srx_version(void);
+const char* srx_last_error(void);
+
+/* Bytes of caller-owned workspace an op needs (0 for FWD / BWD_DATA). */
+size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op);
+
+/* y = act(bias + x (*) w) [+ skip] [relu]
+ * Replaces tf.layers.conv2d / tf.contrib.layers.convolution2d / tf.nn.conv2d +
+ * tf.nn.bias_add + tf.nn.{relu,tanh} and the residual add:
+ *   vdsr/vdsr/model_vdsr.py:62-76 (conv+bias+relu), :85-104 (conv+bias, sd + res)
+ *   espcn/espcn/model_espcn.py:30-62, :117-134
+ *   srcnn/srcnn.py:100-130
+ *   enet/enet/model_enet.py:13-29, :63-113
+ * bias, skip nullable.  skip has the output's shape. */
+int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const float* bias,
+                   const float* skip, float* y, void* ws, size_t ws_bytes, srx_stream_t stream);
+
+/* Conv2DBackpropInput with the UPSTREAM activation gradient fused:
+ *   dx[n,h,w,ci] = sum_{kh,kw,co} dpre[n,h+pt-kh,w+pl-kw,co] * w[kh,kw,ci,co]
+ *   dx_out = dx * act'(x_in)      (x_in = this layer's input = the previous layer's
+ *                                  post-activation output; ReluGrad masks on x_in > 0)
+ * dpre is the gradient w.r.t. this layer's PRE-activation output.  x_in nullable
+ * (then in_act is ignored and plain dx is written).
+ * Replaces the Conv2DBackpropInput + ReluGrad/TanhGrad pairs TF autodiff emits for
+ * optimizer.minimize: vdsr/vdsr/model_vdsr.py:146-148,174;
+ * espcn/espcn/model_espcn.py:87-89; srcnn/srcnn.py:155-157. */
+int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* w,
+                        const float* x_in, int in_act, float* dx_out, void* ws, size_t ws_bytes,
+                        srx_stream_t stream);
+
+/* Conv2DBackpropFilter + BiasAddGrad (+ the L2 regulariser's gradient):
+ *   dw[kh,kw,ci,co] = sum_{n,oh,ow} x[n,oh+kh-pt,ow+kw-pl,ci] * dpre[n,oh,ow,co]
+ *                     + wd_scale * w[kh,kw,ci,co]          (if w_for_decay != NULL)
+ *   dbias[co]       = sum_{n,oh,ow} dpre[n,oh,ow,co]       (if dbias != NULL)
+ * Deterministic: fixed work partition, partials reduced in a fixed order.
+ * Same reference call sites as srx_conv2d_bwd_data; the regulariser is
+ * tf.contrib.layers.l2_regularizer(1e-4): vdsr/vdsr/model_vdsr.py:34,70,93,125. */
+int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* dpre, float* dw,
+                          float* dbias, const float* w_for_decay, float wd_scale, void* ws,
+                          size_t ws_bytes, srx_stream_t stream);
+
+/* dpre = dy * act'(y)  (ReluGrad / TanhGrad on the post-activation tensor). */
+int srx_act_bwd(const float* dy, const float* y, float* dpre, size_t numel, int act,
+                srx_stream_t stream);
+
+/* Sub-pixel (depth-to-space) index map, bit-exact permutation:
+ *   out[n, h*r+dy, w*r+dx, c] = in[n, h, w, (dy*r+dx)*C + c]
+ * in [N,H,W,C*r*r] -> out [N,H*r,W*r,C].  Replaces the host NumPy split/reshape/
+ * concatenate of espcn/espcn/experiment_test.py:171-177 and the TF split/reshape/concat
+ * of espcn/espcn/experiment_train.py:47-56. */
+int srx_depth_to_space(const float* in, float* out, int N, int H, int W, int C, int r,
+                       srx_stream_t stream);
+
+/* Inverse map (HR image -> sub-pixel label layout): in [N,H*r,W*r,C] -> out [N,H,W,C*r*r].
+ * Replaces espcn/espcn/dataset.py:140-156 and espcn/espcn/experiment_test.py:91-96. */
+int srx_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int r,
+                       srx_stream_t stream);
+
+/* tf.losses.mean_squared_error(reduction=MEAN) forward + gradient:
+ *   *loss_out (+)= sum((pred-target)^2) * inv_numel     (device scalar; accumulate != 0 adds)
+ *   dpred      = 2 * (pred-target) * inv_numel          (dpred nullable)
+ * vdsr/vdsr/model_vdsr.py:120-123, espcn/espcn/model_espcn.py:76-77.
+ * scratch: >= srx_reduce_scratch_bytes() bytes of device memory. */
+int srx_mse_fwd_bwd(const float* pred, const float* target, size_t numel, float inv_numel,
+                    float* loss_out, int accumulate, float* dpred, void* scratch,
+                    srx_stream_t stream);
+
+/* *loss_out (+)= scale * sum(w^2)/2  -- tf.contrib.layers.l2_regularizer(scale)(w),
+ * vdsr/vdsr/model_vdsr.py:34,125. */
+int srx_l2_loss(const float* w, size_t numel, float scale, float* loss_out, int accumulate,
+                void* scratch, srx_stream_t stream);
+
+size_t srx_reduce_scratch_bytes(void);
+
+/* TF-1.x AdamOptimizer._apply_dense over a flat parameter buffer ("epsilon hat"):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;
+ *   w -= lr_t*m/(sqrt(v)+eps);  g is multiplied by grad_scale first (1/world for DP sums).
+ * t = 1-based step.  vdsr/vdsr/model_vdsr.py:145-148; espcn/espcn/model_espcn.py:87-89;
+ * srcnn/srcnn.py:155-157 (b1 .5, b2 .9). */
+int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel, float lr,
+                     float beta1, float beta2, float eps, int64_t t, float grad_scale,
+                     srx_stream_t stream);
+
+/* tf.train.MomentumOptimizer(lr, mom) on gradients clipped element-wise to +-cap:
+ *   g=clip(g*grad_scale,-cap,cap); acc=mom*acc+g; w-=lr*acc.
+ * vdsr/vdsr/model_vdsr.py:158-184 (cap = 0.01/lr). */
+int srx_momentum_clip_step(float* w, const float* g, float* acc, size_t numel, float lr,
+                           float momentum, float cap, float grad_scale, srx_stream_t stream);
+
+/* tf.image.psnr(a,b,max_val) per image: out[n] = 20log10(max) - 10log10(mean((a-b)^2)).
+ * vdsr/vdsr/experiment_train.py:80-82, vdsr/vdsr/experiment_evaluate.py:57-60. */
+int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val,
+             srx_stream_t stream);
+
+/* tf.saturate_cast(x*127.5+127.5, uint8): clamp to [0,255], truncate.
+ * vdsr/vdsr/experiment_resolve.py:65-69, espcn/espcn/experiment_train.py:58. */
+int srx_saturate_u8(const float* x, uint8_t* out, size_t numel, srx_stream_t stream);
+
+/* out = a*x + b (elementwise); used for the [0,255] <-> [-1,1] maps at the model edge
+ * (espcn/espcn/experiment_test.py:160,179). */
+int srx_affine(const float* x, float* out, size_t numel, float a, float b, srx_stream_t stream);
+
+/* tf.image.resize_nearest_neighbor by an integer factor (pixel replication):
+ * in [N,H,W,C] -> out [N,H*f,W*f,C].  enet/enet/model_enet.py:78-80. */
+int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f,
+                         srx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H_ */

@@ -1,0 +1,83 @@
+"""ctypes binding of libsrx.so (C ABI: include/srx.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Nothing here imports the oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsrx.so')
+
+SRX_OK = 0
+PAD_SAME, PAD_VALID = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+OP_FWD, OP_BWD_DATA, OP_BWD_FILTER = 0, 1, 2
+
+ACT_BY_NAME = {None: ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH,
+               'lrelu': ACT_LRELU, 'leaky_relu': ACT_LRELU, 'sigmoid': ACT_SIGMOID}
+PAD_BY_NAME = {'same': PAD_SAME, 'valid': PAD_VALID}
+
+# every symbol include/srx.h declares
+EXPORTS = [
+    'srx_version', 'srx_last_error', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
+    'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_act_bwd', 'srx_depth_to_space',
+    'srx_space_to_depth', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
+    'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_psnr', 'srx_saturate_u8', 'srx_affine',
+    'srx_upsample_nearest',
+]
+
+
+class SrxError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_mode', 'act',
+                 'post_add_relu', 'precision')]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsrx.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrxError('libsrx.so not found at %s -- build it with `make -C %s` (or '
+                       '__graft_entry__.build()); there is no CPU fallback' %
+                       (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, i, f = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float
+    dp = ctypes.POINTER(ConvDesc)
+    L.srx_version.restype = ctypes.c_char_p
+    L.srx_last_error.restype = ctypes.c_char_p
+    L.srx_conv2d_workspace_bytes.argtypes = [dp, i]
+    L.srx_conv2d_workspace_bytes.restype = sz
+    L.srx_reduce_scratch_bytes.restype = sz
+    L.srx_conv2d_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.srx_conv2d_bwd_data.argtypes = [dp, vp, vp, vp, i, vp, vp, sz, vp]
+    L.srx_conv2d_bwd_filter.argtypes = [dp, vp, vp, vp, vp, vp, f, vp, sz, vp]
+    L.srx_act_bwd.argtypes = [vp, vp, vp, sz, i, vp]
+    L.srx_depth_to_space.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srx_space_to_depth.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srx_mse_fwd_bwd.argtypes = [vp, vp, sz, f, vp, i, vp, vp, vp]
+    L.srx_l2_loss.argtypes = [vp, sz, f, vp, i, vp, vp]
+    L.srx_adam_tf_step.argtypes = [vp, vp, vp, vp, sz, f, f, f, f, ctypes.c_int64, f, vp]
+    L.srx_momentum_clip_step.argtypes = [vp, vp, vp, sz, f, f, f, f, vp]
+    L.srx_psnr.argtypes = [vp, vp, vp, i, sz, f, vp]
+    L.srx_saturate_u8.argtypes = [vp, vp, sz, vp]
+    L.srx_affine.argtypes = [vp, vp, sz, f, f, vp]
+    L.srx_upsample_nearest.argtypes = [vp, vp, i, i, i, i, i, vp]
+    for name in EXPORTS:
+        getattr(L, name)          # AttributeError if the library is stale
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != SRX_OK:
+        raise SrxError('%s failed (status %d): %s' % (what, rc, lib().srx_last_error().decode()))

@@ -1,0 +1,21 @@
+// elementwise.h -- internal launch prototypes of elementwise.hip
+#pragma once
+#include "conv_kernels.hip.h"
+
+namespace srx {
+constexpr int kReduceBlocks = 1024;  // partial slots a reduction may use (srx_reduce_scratch_bytes)
+
+hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse, hipStream_t s);
+hipError_t launch_mse(const float* pred, const float* target, size_t n, float inv, float* loss, int accumulate,
+                      float* dpred, float* scratch, hipStream_t s);
+hipError_t launch_l2(const float* w, size_t n, float scale, float* loss, int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+                       float gs, hipStream_t s);
+hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float lr, float mom, float cap, float gs,
+                           hipStream_t s);
+hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s);
+hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b, hipStream_t s);
+hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s);
+hipError_t launch_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val, hipStream_t s);
+hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, hipStream_t s);
+}  // namespace srx

@@ -1,0 +1,365 @@
+// elementwise.hip -- HBM-bound kernels of the path: sub-pixel index maps, loss, optimizers,
+// metrics.  All are grid-stride, 16 B per lane where the layout allows.
+#include "elementwise.h"
+
+namespace srx {
+
+// ---------------------------------------------------------------------------------------------
+// depth_to_space / space_to_depth.
+// For one LR row (n,h) the r HR rows it produces are CONTIGUOUS in the output and cover exactly
+// the same flat range [blk*B, (blk+1)*B), B = W*r*r*C, as the LR row does in the input.  So the
+// map is one fixed permutation applied independently to every block of B floats:
+//   d2s: out[dy*(W*rC) + w*rC + j] = in[w*(r*rC) + dy*rC + j],   rC = r*C
+// A workgroup stages RB blocks into LDS with coalesced 16-B loads, gathers from LDS, and writes
+// coalesced 16-B stores: HBM traffic is exactly read-once + write-once.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d2s_src(int oo, int W, int rC, int r, float inv_WrC, float inv_rC) {
+    // oo = dy*(W*rC) + w*rC + j  ->  w*(r*rC) + dy*rC + j
+    const int WrC = W * rC;
+    int dy = (int)(((float)oo + 0.5f) * inv_WrC);
+    dy -= (dy * WrC > oo);
+    dy += ((dy + 1) * WrC <= oo);
+    const int rest = oo - dy * WrC;
+    int w = (int)(((float)rest + 0.5f) * inv_rC);
+    w -= (w * rC > rest);
+    w += ((w + 1) * rC <= rest);
+    const int j = rest - w * rC;
+    return w * (r * rC) + dy * rC + j;
+}
+
+__device__ __forceinline__ int s2d_src(int oo, int W, int rC, int r, float inv_rrC, float inv_rC) {
+    // oo = w*(r*rC) + dy*rC + j  ->  dy*(W*rC) + w*rC + j
+    const int rrC = r * rC;
+    int w = (int)(((float)oo + 0.5f) * inv_rrC);
+    w -= (w * rrC > oo);
+    w += ((w + 1) * rrC <= oo);
+    const int rest = oo - w * rrC;
+    int dy = (int)(((float)rest + 0.5f) * inv_rC);
+    dy -= (dy * rC > rest);
+    dy += ((dy + 1) * rC <= rest);
+    const int j = rest - dy * rC;
+    return dy * (W * rC) + w * rC + j;
+}
+
+// chunk = RB blocks (chunk_floats = RB*B, a multiple of 4 except possibly the last chunk)
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           size_t total, int B, int chunk_floats, int W, int rC,
+                                                           int r) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float inv_B = 1.0f / (float)B;
+    const float inv_a = INVERSE ? 1.0f / (float)(r * rC) : 1.0f / (float)(W * rC);
+    const float inv_rC = 1.0f / (float)rC;
+    for (size_t c0 = (size_t)blockIdx.x * chunk_floats; c0 < total; c0 += (size_t)gridDim.x * chunk_floats) {
+        const int n = (int)((total - c0 < (size_t)chunk_floats) ? (total - c0) : (size_t)chunk_floats);
+        const int n4 = n >> 2;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n4; i += 256)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(in + c0)[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) lds[i] = in[c0 + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = 4 * i + e;
+                int blk = (int)(((float)o + 0.5f) * inv_B);
+                blk -= (blk * B > o);
+                blk += ((blk + 1) * B <= o);
+                const int oo = o - blk * B;
+                const int src = INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC);
+                v[e] = lds[blk * B + src];
+            }
+            reinterpret_cast<f32x4*>(out + c0)[i] = v;
+        }
+        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) {
+            int blk = (int)(((float)o + 0.5f) * inv_B);
+            blk -= (blk * B > o);
+            blk += ((blk + 1) * B <= o);
+            const int oo = o - blk * B;
+            const int src = INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC);
+            out[c0 + o] = lds[blk * B + src];
+        }
+    }
+}
+
+// Fallback for rows too long for LDS: direct gather (reads stay inside one B-float block).
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void subpixel_direct_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              size_t total, int B, int W, int rC, int r) {
+    const float inv_a = INVERSE ? 1.0f / (float)(r * rC) : 1.0f / (float)(W * rC);
+    const float inv_rC = 1.0f / (float)rC;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const size_t blk = o / (size_t)B;
+        const int oo = (int)(o - blk * (size_t)B);
+        const int src = INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC);
+        out[o] = in[blk * (size_t)B + src];
+    }
+}
+
+hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
+                           hipStream_t s) {
+    const int rC = r * C;
+    const size_t B = (size_t)W * r * rC;
+    const size_t total = (size_t)N * H * B;
+    if (total == 0) return hipSuccess;
+    const size_t lds_cap = 48 * 1024;
+    // RB blocks per chunk: chunk must be a multiple of 4 floats so every chunk start is 16-B aligned
+    size_t RB = 4;
+    if (B % 4 == 0) RB = 1; else if (B % 2 == 0) RB = 2;
+    if (RB * B * 4 <= lds_cap && B < (1u << 20)) {
+        while (2 * RB * B * 4 <= 24 * 1024) RB *= 2;   // ~16-24 KiB chunks: >= 6 workgroups per CU
+        const int chunk = (int)(RB * B);
+        size_t nchunks = (total + chunk - 1) / chunk;
+        int grid = (int)(nchunks < 4096 ? nchunks : 4096);
+        if (inverse)
+            hipLaunchKernelGGL(subpixel_lds_kernel<true>, dim3(grid), dim3(256), chunk * 4, s, in, out, total, (int)B,
+                               chunk, W, rC, r);
+        else
+            hipLaunchKernelGGL(subpixel_lds_kernel<false>, dim3(grid), dim3(256), chunk * 4, s, in, out, total, (int)B,
+                               chunk, W, rC, r);
+    } else {
+        if (B >= (1u << 22)) return hipErrorInvalidValue;
+        size_t nb = (total + 255) / 256;
+        int grid = (int)(nb < 8192 ? nb : 8192);
+        if (inverse)
+            hipLaunchKernelGGL(subpixel_direct_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, total, (int)B, W, rC, r);
+        else
+            hipLaunchKernelGGL(subpixel_direct_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, total, (int)B, W, rC, r);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions: per-block partials (fixed grid) -> one finishing block, double accumulate.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = (threadIdx.x < (blockDim.x >> 6)) ? sh[threadIdx.x] : 0.f;
+    if (wave == 0) t = wave_sum(t);
+    return t;  // valid in wave 0
+}
+
+// MODE 0: (a-b)^2, also writes dpred = 2*(a-b)*inv ; MODE 1: a^2
+template <int MODE>
+__global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         size_t n, float inv, float* __restrict__ dpred,
+                                                         float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+        if (MODE == 0) {
+            const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+            va -= vb;
+            if (dpred) reinterpret_cast<f32x4*>(dpred)[i] = va * (2.0f * inv);
+        }
+        acc += va[0] * va[0] + va[1] * va[1] + va[2] * va[2] + va[3] * va[3];
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            float d = a[i];
+            if (MODE == 0) {
+                d -= b[i];
+                if (dpred) dpred[i] = d * (2.0f * inv);
+            }
+            acc += d * d;
+        }
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partial, int n, float scale,
+                                                         float* __restrict__ out, int accumulate) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)(sh[0] * (double)scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+static int reduce_grid(size_t n) {
+    size_t nb = ((n >> 2) + 255) / 256;
+    if (nb < 1) nb = 1;
+    return (int)(nb < (size_t)kReduceBlocks ? nb : (size_t)kReduceBlocks);
+}
+
+hipError_t launch_mse(const float* pred, const float* target, size_t n, float inv, float* loss, int accumulate,
+                      float* dpred, float* scratch, hipStream_t s) {
+    const int grid = reduce_grid(n);
+    hipLaunchKernelGGL(sq_partial_kernel<0>, dim3(grid), dim3(256), 0, s, pred, target, n, inv, dpred, scratch);
+    if (loss) hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, scratch, grid, inv, loss, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_l2(const float* w, size_t n, float scale, float* loss, int accumulate, float* scratch,
+                     hipStream_t s) {
+    const int grid = reduce_grid(n);
+    hipLaunchKernelGGL(sq_partial_kernel<1>, dim3(grid), dim3(256), 0, s, w, (const float*)nullptr, n, 0.f,
+                       (float*)nullptr, scratch);
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, scratch, grid, 0.5f * scale, loss, accumulate);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizers (flat buffers)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                      float lr_t, float b1, float b2, float eps, float gs) {
+    const size_t n4 = n >> 2;
+    const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * gs;
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] = b1 * mv[e] + ob1 * gv[e];
+            vv[e] = b2 * vv[e] + ob2 * gv[e] * gv[e];
+            wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(w)[i] = wv;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float gi = g[i] * gs;
+            const float mi = b1 * m[i] + ob1 * gi;
+            const float vi = b2 * v[i] + ob2 * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void momentum_clip_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                            float* __restrict__ acc, size_t n, float lr, float mom,
+                                                            float cap, float gs) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * gs;
+        gi = fminf(fmaxf(gi, -cap), cap);
+        const float a = mom * acc[i] + gi;
+        acc[i] = a;
+        w[i] -= lr * a;
+    }
+}
+
+static int ew_grid(size_t n, int per_thread) {
+    size_t nb = (n / per_thread + 255) / 256;
+    if (nb < 1) nb = 1;
+    return (int)(nb < 2048 ? nb : 2048);
+}
+
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                       float eps, float gs, hipStream_t s) {
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, gs);
+    return hipGetLastError();
+}
+
+hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float lr, float mom, float cap, float gs,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(momentum_clip_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, w, g, acc, n, lr, mom, cap, gs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// misc elementwise
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dpre, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dpre[i] = dy[i] * act_grad_from_y(y[i], act);
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n,
+                                                     float a, float b) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = a * x[i] + b;
+}
+
+__global__ __launch_bounds__(256) void saturate_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
+                                                          size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = x[i] * 127.5f + 127.5f;
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        out[i] = (uint8_t)v;  // truncation toward zero, as tf.saturate_cast
+    }
+}
+
+__global__ __launch_bounds__(256) void psnr_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, size_t per_image, float max_val) {
+    __shared__ float sh[4];
+    const float* pa = a + (size_t)blockIdx.x * per_image;
+    const float* pb = b + (size_t)blockIdx.x * per_image;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < per_image; i += 256) {
+        const float d = pa[i] - pb[i];
+        acc += d * d;
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = 20.0f * log10f(max_val) - 10.0f * log10f(t / (float)per_image);
+}
+
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int N, int H, int W, int C, int f) {
+    const size_t total = (size_t)N * H * f * W * f * C;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        size_t t = o / C;
+        const int ow = (int)(t % ((size_t)W * f));
+        t /= (size_t)W * f;
+        const int oh = (int)(t % ((size_t)H * f));
+        const int n = (int)(t / ((size_t)H * f));
+        out[o] = in[(((size_t)n * H + oh / f) * W + ow / f) * C + c];
+    }
+}
+
+hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, y, dpre, n, act);
+    return hipGetLastError();
+}
+hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b, hipStream_t s) {
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, x, out, n, a, b);
+    return hipGetLastError();
+}
+hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(saturate_u8_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, x, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(psnr_kernel, dim3(N), dim3(256), 0, s, a, b, out, per_image, max_val);
+    return hipGetLastError();
+}
+hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, hipStream_t s) {
+    const size_t total = (size_t)N * H * f * W * f * C;
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, out, N, H, W, C, f);
+    return hipGetLastError();
+}
+
+}  // namespace srx

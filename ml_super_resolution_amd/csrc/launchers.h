@@ -1,0 +1,44 @@
+// launchers.h -- internal: typed launch entry points for the kernel instances, one per
+// translation unit so the instances compile in parallel.
+#pragma once
+#include "conv_kernels.hip.h"
+
+namespace srx {
+
+struct ConvKey {
+    int kh, kw, cinp, nch;
+    bool wt;
+};
+
+// Each returns true if the key belongs to that unit (then *err holds the launch status).
+bool launch_conv_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_conv_k3c32(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_conv_c4(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_conv_misc(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+
+hipError_t launch_reduce_partials(const float* part, int G, size_t n, float* out, const float* w, float wd, hipStream_t s);
+
+template <typename K, typename A>
+inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hipStream_t s) {
+    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent and cheap.
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+#define SRX_CONV_CASE(KH, KW, CINP, NCH, WT, MINW)                                                        \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt == WT) {                       \
+        *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW>, a, grid, lds, s);           \
+        return true;                                                                                      \
+    }
+#define SRX_WGRAD_CASE(KH, KW, CINP, NCH, MINW)                                                           \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH) {                                     \
+        *err = launch_with_lds(wgrad_mfma_kernel<KH, KW, CINP, NCH, MINW>, a, grid, lds, s);              \
+        return true;                                                                                      \
+    }
+
+}  // namespace srx

@@ -1,0 +1,330 @@
+// srx_api.hip -- the C ABI of libsrx.so (include/srx.h): argument checking, tile planning,
+// kernel-instance dispatch.  No device synchronisation, no allocation.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/srx.h"
+#include "elementwise.h"
+#include "launchers.h"
+
+using namespace srx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr size_t kLdsBudget = 80 * 1024;  // two workgroups per CU (160 KiB)
+constexpr int kMaxGrid = 512;             // 2 persistent workgroups x 256 CUs
+
+struct Plan {
+    int KH, KW, cinp, nch;
+    int pad_t, pad_l, OH, OW;
+    int TH, TW, NTX, RS;
+    int units_total, grid;
+    size_t lds_bytes;
+};
+
+int pad_channels(int c) { return c <= 4 ? 4 : (c <= 32 ? 32 : (c <= 64 ? 64 : -1)); }
+int chunks_for(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : (c <= 64 ? 4 : -1)); }
+
+// in_c / out_c: channels of the tensor staged through LDS / produced by the kernel.
+// (H,W) staged tensor dims, (OH,OW) produced tensor dims, pads relative to the staged tensor.
+int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, int KW, int pad_t, int pad_l,
+              Plan* p) {
+    p->KH = KH; p->KW = KW;
+    p->cinp = pad_channels(in_c);
+    p->nch = chunks_for(out_c);
+    if (p->cinp < 0 || p->nch < 0)
+        return fail(SRX_ERR_UNSUPPORTED, "channel counts %d->%d outside the kernel set (<=64)", in_c, out_c);
+    p->pad_t = pad_t; p->pad_l = pad_l; p->OH = OH; p->OW = OW;
+    const int ps = (p->cinp == 4) ? 4 : p->cinp + 4;
+    const size_t slot_bytes = (size_t)ps * 4;
+    const size_t max_slots = kLdsBudget / slot_bytes;
+    // full-width tiles: the zero column(s) left of row r+1 double as the right padding of row r
+    int RS = W + pad_l;
+    if (RS < OW + KW - 1 - (KW - 1 - pad_l)) RS = OW + pad_l;
+    int TW = OW, NTX = 1;
+    long th_max = ((long)max_slots - (KW - 1)) / RS - (KH - 1);
+    if (th_max < 1) {
+        // column tiling: each tile carries its own halo columns; narrow the tile until it fits
+        for (TW = 32; TW >= 8; TW >>= 1) {
+            RS = TW + KW - 1;
+            th_max = ((long)max_slots - (KW - 1)) / RS - (KH - 1);
+            if (th_max >= 1) break;
+        }
+        if (th_max < 1) return fail(SRX_ERR_UNSUPPORTED, "filter %dx%d too large for the LDS tile", KH, KW);
+        NTX = (OW + TW - 1) / TW;
+    }
+    if (th_max > OH) th_max = OH;
+    if (th_max > 16) th_max = 16;
+    // keep enough tiles in flight to occupy the chip on small problems
+    const long rows_total = (long)N * NTX * OH;
+    while (th_max > 1 && rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) th_max -= 1;
+    // among the tallest candidates pick the one wasting the fewest lanes of the 16-pixel sub-tiles
+    int best = (int)th_max;
+    double best_eff = 0.0;
+    for (int th = (int)th_max; th >= (int)((th_max + 1) / 2) && th >= 1; --th) {
+        const int px = th * TW;
+        const double eff = (double)px / (16.0 * ((px + 15) / 16));
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = th; }
+    }
+    p->TH = best; p->TW = TW; p->NTX = NTX; p->RS = RS;
+    p->units_total = (int)rows_total;
+    long g = rows_total / p->TH;
+    if (g < 1) g = 1;
+    p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
+    p->lds_bytes = ((size_t)(p->TH + KH - 1) * RS + (KW - 1)) * slot_bytes;
+    return SRX_OK;
+}
+
+int check_desc(const srx_conv_desc* d) {
+    if (!d) return fail(SRX_ERR_BAD_ARG, "null descriptor");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0)
+        return fail(SRX_ERR_BAD_ARG, "non-positive dimension in descriptor");
+    if (d->stride != 1) return fail(SRX_ERR_UNSUPPORTED, "stride %d: only stride 1 is implemented", d->stride);
+    if (d->pad_mode != SRX_PAD_SAME && d->pad_mode != SRX_PAD_VALID) return fail(SRX_ERR_BAD_ARG, "bad pad_mode");
+    if (d->act < SRX_ACT_NONE || d->act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad activation");
+    if (d->precision != 0) return fail(SRX_ERR_UNSUPPORTED, "precision mode %d not implemented", d->precision);
+    if (d->pad_mode == SRX_PAD_VALID && (d->H < d->KH || d->W < d->KW))
+        return fail(SRX_ERR_BAD_ARG, "VALID convolution with input smaller than the filter");
+    if ((long)d->N * d->H * d->W * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1L << 31) * 4)
+        return fail(SRX_ERR_UNSUPPORTED, "tensor too large for 32-bit unit indexing");
+    return SRX_OK;
+}
+
+void geometry(const srx_conv_desc* d, int* pad_t, int* pad_l, int* OH, int* OW) {
+    if (d->pad_mode == SRX_PAD_SAME) {
+        *pad_t = (d->KH - 1) / 2; *pad_l = (d->KW - 1) / 2; *OH = d->H; *OW = d->W;
+    } else {
+        *pad_t = 0; *pad_l = 0; *OH = d->H - d->KH + 1; *OW = d->W - d->KW + 1;
+    }
+}
+
+int dispatch_conv(const Plan& p, bool wt, const ConvArgs& a, hipStream_t s) {
+    ConvKey k{p.KH, p.KW, p.cinp, p.nch, wt};
+    hipError_t err = hipSuccess;
+    bool hit = launch_conv_k3c64(k, a, p.grid, p.lds_bytes, s, &err) ||
+               launch_conv_k3c32(k, a, p.grid, p.lds_bytes, s, &err) ||
+               launch_conv_c4(k, a, p.grid, p.lds_bytes, s, &err) ||
+               launch_conv_misc(k, a, p.grid, p.lds_bytes, s, &err) ||
+               launch_conv_generic(k, a, p.grid, p.lds_bytes, s, &err);
+    if (!hit)
+        return fail(SRX_ERR_UNSUPPORTED, "no kernel instance for %dx%d, Cin<=%d, Cout chunks %d, %s", p.KH, p.KW,
+                    p.cinp, p.nch, wt ? "dgrad" : "fwd");
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+    return SRX_OK;
+}
+
+void fill_conv_args(ConvArgs* a, const Plan& p, int N, int H, int W, int in_c, int out_c) {
+    a->N = N; a->H = H; a->W = W; a->OH = p.OH; a->OW = p.OW; a->Cin = in_c; a->Cout = out_c;
+    a->pad_t = p.pad_t; a->pad_l = p.pad_l;
+    a->TH = p.TH; a->TW = p.TW; a->NTX = p.NTX; a->RS = p.RS;
+    a->units_total = p.units_total;
+    a->inv_rs = 1.0f / (float)p.RS;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* srx_version(void) { return "srx 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+const char* srx_last_error(void) { return g_err; }
+size_t srx_reduce_scratch_bytes(void) { return (size_t)kReduceBlocks * sizeof(float); }
+
+size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op) {
+    if (check_desc(d) != SRX_OK) return 0;
+    if (op != SRX_OP_BWD_FILTER) return 0;
+    int pt, pl, OH, OW;
+    geometry(d, &pt, &pl, &OH, &OW);
+    Plan p;
+    if (make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p) != SRX_OK) return 0;
+    const size_t per = (size_t)d->KH * d->KW * d->Cin * d->Cout + (size_t)d->Cout;
+    return (size_t)p.grid * per * sizeof(float);
+}
+
+int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const float* bias, const float* skip,
+                   float* y, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (skip && !aligned16(skip)))
+        return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    int pt, pl, OH, OW;
+    geometry(d, &pt, &pl, &OH, &OW);
+    Plan p;
+    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
+    if (rc) return rc;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.mask = nullptr; a.y = y;
+    fill_conv_args(&a, p, d->N, d->H, d->W, d->Cin, d->Cout);
+    a.act = d->act; a.post_relu = d->post_add_relu; a.mask_act = 0;
+    return dispatch_conv(p, false, a, (hipStream_t)stream);
+}
+
+int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* w, const float* x_in, int in_act,
+                        float* dx_out, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dpre || !w || !dx_out) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (!aligned16(dpre) || !aligned16(w) || !aligned16(dx_out) || (x_in && !aligned16(x_in)))
+        return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (in_act < SRX_ACT_NONE || in_act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad in_act");
+    int pt, pl, OH, OW;
+    geometry(d, &pt, &pl, &OH, &OW);
+    // the kernel stages dpre [N,OH,OW,Cout] and produces dx [N,H,W,Cin]; full-correlation padding
+    Plan p;
+    rc = make_plan(d->N, OH, OW, d->H, d->W, d->Cout, d->Cin, d->KH, d->KW, d->KH - 1 - pt, d->KW - 1 - pl, &p);
+    if (rc) return rc;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dpre; a.w = w; a.bias = nullptr; a.skip = nullptr; a.mask = x_in; a.y = dx_out;
+    fill_conv_args(&a, p, d->N, OH, OW, d->Cout, d->Cin);
+    a.act = SRX_ACT_NONE; a.post_relu = 0; a.mask_act = in_act;
+    return dispatch_conv(p, true, a, (hipStream_t)stream);
+}
+
+int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* dpre, float* dw, float* dbias,
+                          const float* w_for_decay, float wd_scale, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !dpre || !dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (!aligned16(x) || !aligned16(dpre)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    int pt, pl, OH, OW;
+    geometry(d, &pt, &pl, &OH, &OW);
+    Plan p;
+    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
+    if (rc) return rc;
+    const size_t wn = (size_t)d->KH * d->KW * d->Cin * d->Cout;
+    const size_t need = (size_t)p.grid * (wn + (size_t)d->Cout) * sizeof(float);
+    if (!ws || ws_bytes < need)
+        return fail(SRX_ERR_WORKSPACE, "bwd_filter needs %zu workspace bytes, got %zu", need, ws_bytes);
+    if (!aligned16(ws)) return fail(SRX_ERR_ALIGN, "workspace must be 16-byte aligned");
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dpre = dpre;
+    a.part_dw = (float*)ws;
+    a.part_db = (float*)ws + (size_t)p.grid * wn;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.OH = OH; a.OW = OW; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.pad_t = pt; a.pad_l = pl; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
+    a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
+    ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
+    hipError_t err = hipSuccess;
+    hipStream_t s = (hipStream_t)stream;
+    if (!launch_wgrad(k, a, p.grid, p.lds_bytes, s, &err))
+        return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
+                    p.nch);
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
+    err = launch_reduce_partials(a.part_dw, p.grid, wn, dw, w_for_decay, wd_scale, s);
+    if (err == hipSuccess && dbias)
+        err = launch_reduce_partials(a.part_db, p.grid, (size_t)d->Cout, dbias, nullptr, 0.f, s);
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "reduce launch failed: %s", hipGetErrorString(err));
+    return SRX_OK;
+}
+
+#define SRX_CHECK_LAUNCH(expr, what)                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(SRX_ERR_LAUNCH, what ": %s", hipGetErrorString(e_)); \
+        return SRX_OK;                                                                       \
+    } while (0)
+
+int srx_act_bwd(const float* dy, const float* y, float* dpre, size_t numel, int act, srx_stream_t stream) {
+    if (!dy || !y || !dpre) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (act < SRX_ACT_NONE || act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad activation");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_act_bwd(dy, y, dpre, numel, act, (hipStream_t)stream), "act_bwd");
+}
+
+static int subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inv, srx_stream_t stream) {
+    if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (N < 0 || H < 0 || W < 0 || C <= 0 || r <= 0) return fail(SRX_ERR_BAD_ARG, "bad sub-pixel dims");
+    if (!aligned16(in) || !aligned16(out)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (in == out) return fail(SRX_ERR_BAD_ARG, "sub-pixel map cannot run in place");
+    if (N == 0 || H == 0 || W == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_subpixel(in, out, N, H, W, C, r, inv, (hipStream_t)stream), "sub-pixel map");
+}
+
+int srx_depth_to_space(const float* in, float* out, int N, int H, int W, int C, int r, srx_stream_t stream) {
+    return subpixel(in, out, N, H, W, C, r, false, stream);
+}
+int srx_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int r, srx_stream_t stream) {
+    return subpixel(in, out, N, H, W, C, r, true, stream);
+}
+
+int srx_mse_fwd_bwd(const float* pred, const float* target, size_t numel, float inv_numel, float* loss_out,
+                    int accumulate, float* dpred, void* scratch, srx_stream_t stream) {
+    if (!pred || !target || !scratch) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (!aligned16(pred) || !aligned16(target) || (dpred && !aligned16(dpred)))
+        return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_mse(pred, target, numel, inv_numel, loss_out, accumulate, dpred, (float*)scratch,
+                                (hipStream_t)stream), "mse");
+}
+
+int srx_l2_loss(const float* w, size_t numel, float scale, float* loss_out, int accumulate, void* scratch,
+                srx_stream_t stream) {
+    if (!w || !loss_out || !scratch) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (!aligned16(w)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_l2(w, numel, scale, loss_out, accumulate, (float*)scratch, (hipStream_t)stream), "l2");
+}
+
+int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel, float lr, float beta1, float beta2,
+                     float eps, int64_t t, float grad_scale, srx_stream_t stream) {
+    if (!w || !g || !m || !v) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (t < 1) return fail(SRX_ERR_BAD_ARG, "Adam step count t must be >= 1");
+    if (!aligned16(w) || !aligned16(g) || !aligned16(m) || !aligned16(v))
+        return fail(SRX_ERR_ALIGN, "flat buffers must be 16-byte aligned");
+    if (numel == 0) return SRX_OK;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+    SRX_CHECK_LAUNCH(launch_adam(w, g, m, v, numel, (float)lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream),
+                     "adam");
+}
+
+int srx_momentum_clip_step(float* w, const float* g, float* acc, size_t numel, float lr, float momentum, float cap,
+                           float grad_scale, srx_stream_t stream) {
+    if (!w || !g || !acc) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_momentum(w, g, acc, numel, lr, momentum, cap, grad_scale, (hipStream_t)stream), "momentum");
+}
+
+int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val, srx_stream_t stream) {
+    if (!a || !b || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || per_image == 0) return fail(SRX_ERR_BAD_ARG, "bad psnr dims");
+    SRX_CHECK_LAUNCH(launch_psnr(a, b, out, N, per_image, max_val, (hipStream_t)stream), "psnr");
+}
+
+int srx_saturate_u8(const float* x, uint8_t* out, size_t numel, srx_stream_t stream) {
+    if (!x || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_saturate_u8(x, out, numel, (hipStream_t)stream), "saturate_u8");
+}
+
+int srx_affine(const float* x, float* out, size_t numel, float a, float b, srx_stream_t stream) {
+    if (!x || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_affine(x, out, numel, a, b, (hipStream_t)stream), "affine");
+}
+
+int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, srx_stream_t stream) {
+    if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || f <= 0) return fail(SRX_ERR_BAD_ARG, "bad upsample dims");
+    SRX_CHECK_LAUNCH(launch_upsample_nearest(in, out, N, H, W, C, f, (hipStream_t)stream), "upsample");
+}
+
+}  // extern "C"

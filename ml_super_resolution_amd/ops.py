@@ -1,0 +1,189 @@
+"""Thin op wrappers over the C ABI.  Tensors are torch CUDA(ROCm) float32, NHWC activations,
+HWIO filters.  Every call is asynchronous on torch's current stream."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_BY_NAME, PAD_BY_NAME, ConvDesc, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError('%s must be a contiguous float32 tensor on the GPU' % name)
+
+
+def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False):
+    N, H, W, Cin = x_shape
+    KH, KW, wci, Cout = w_shape
+    if wci != Cin:
+        raise ValueError('filter Cin %d != input channels %d' % (wci, Cin))
+    return ConvDesc(N, H, W, Cin, Cout, KH, KW, 1, PAD_BY_NAME[padding.lower()],
+                    ACT_BY_NAME[act] if not isinstance(act, int) else act, int(post_add_relu), 0)
+
+
+def out_shape(d):
+    if d.pad_mode == _lib.PAD_SAME:
+        return (d.N, d.H, d.W, d.Cout)
+    return (d.N, d.H - d.KH + 1, d.W - d.KW + 1, d.Cout)
+
+
+_scratch = {}
+
+
+def reduce_scratch(device):
+    key = (device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(lib().srx_reduce_scratch_bytes() // 4, dtype=torch.float32, device=device)
+    return _scratch[key]
+
+
+def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_relu=False, out=None):
+    """act(bias + x (*) w) [+ skip] [relu] -- srx_conv2d_fwd."""
+    for t, n in ((x, 'x'), (w, 'w'), (bias, 'bias'), (skip, 'skip')):
+        _chk(t, n)
+    d = conv_desc(x.shape, w.shape, padding, act, post_add_relu)
+    y = out if out is not None else torch.empty(out_shape(d), dtype=torch.float32, device=x.device)
+    check(lib().srx_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(skip), _ptr(y), None, 0,
+                               _stream()), 'srx_conv2d_fwd')
+    return y
+
+
+def conv2d_bwd_data(dpre, w, x_shape, padding='same', x_in=None, in_act=None, out=None):
+    """dx * act'(x_in) -- srx_conv2d_bwd_data."""
+    for t, n in ((dpre, 'dpre'), (w, 'w'), (x_in, 'x_in')):
+        _chk(t, n)
+    d = conv_desc(x_shape, w.shape, padding)
+    dx = out if out is not None else torch.empty(tuple(x_shape), dtype=torch.float32, device=dpre.device)
+    check(lib().srx_conv2d_bwd_data(ctypes.byref(d), _ptr(dpre), _ptr(w), _ptr(x_in), ACT_BY_NAME[in_act],
+                                    _ptr(dx), None, 0, _stream()), 'srx_conv2d_bwd_data')
+    return dx
+
+
+def bwd_filter_workspace_bytes(x_shape, w_shape, padding='same'):
+    d = conv_desc(x_shape, w_shape, padding)
+    return lib().srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_BWD_FILTER)
+
+
+def conv2d_bwd_filter(x, dpre, w_shape, padding='same', w_for_decay=None, wd_scale=0.0, dw=None, dbias=None,
+                      want_dbias=True, workspace=None):
+    """(dw, dbias) -- srx_conv2d_bwd_filter."""
+    for t, n in ((x, 'x'), (dpre, 'dpre'), (w_for_decay, 'w_for_decay')):
+        _chk(t, n)
+    d = conv_desc(x.shape, w_shape, padding)
+    if dw is None:
+        dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    if dbias is None and want_dbias:
+        dbias = torch.empty((w_shape[3],), dtype=torch.float32, device=x.device)
+    need = lib().srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_BWD_FILTER)
+    if workspace is None:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib().srx_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dpre), _ptr(dw), _ptr(dbias),
+                                      _ptr(w_for_decay), float(wd_scale), _ptr(workspace),
+                                      workspace.numel() * 4, _stream()), 'srx_conv2d_bwd_filter')
+    return dw, dbias
+
+
+def act_bwd(dy, y, act, out=None):
+    _chk(dy, 'dy'); _chk(y, 'y')
+    out = out if out is not None else torch.empty_like(dy)
+    check(lib().srx_act_bwd(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), ACT_BY_NAME[act], _stream()), 'srx_act_bwd')
+    return out
+
+
+def depth_to_space(x, r, out=None):
+    """[N,H,W,C*r*r] -> [N,H*r,W*r,C], TF channel order (dy,dx,c)."""
+    _chk(x, 'x')
+    N, H, W, D = x.shape
+    if D % (r * r):
+        raise ValueError('depth %d not divisible by r*r=%d' % (D, r * r))
+    C = D // (r * r)
+    out = out if out is not None else torch.empty((N, H * r, W * r, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_depth_to_space(_ptr(x), _ptr(out), N, H, W, C, r, _stream()), 'srx_depth_to_space')
+    return out
+
+
+def space_to_depth(x, r, out=None):
+    """[N,H*r,W*r,C] -> [N,H,W,C*r*r]."""
+    _chk(x, 'x')
+    N, HR, WR, C = x.shape
+    if HR % r or WR % r:
+        raise ValueError('spatial dims %dx%d not divisible by r=%d' % (HR, WR, r))
+    H, W = HR // r, WR // r
+    out = out if out is not None else torch.empty((N, H, W, C * r * r), dtype=torch.float32, device=x.device)
+    check(lib().srx_space_to_depth(_ptr(x), _ptr(out), N, H, W, C, r, _stream()), 'srx_space_to_depth')
+    return out
+
+
+def mse_fwd_bwd(pred, target, loss_out, inv_numel=None, accumulate=False, dpred=None, want_grad=True):
+    """loss_out (+)= sum((pred-target)^2)*inv_numel; returns dpred = 2*(pred-target)*inv_numel."""
+    _chk(pred, 'pred'); _chk(target, 'target')
+    if inv_numel is None:
+        inv_numel = 1.0 / pred.numel()
+    if dpred is None and want_grad:
+        dpred = torch.empty_like(pred)
+    check(lib().srx_mse_fwd_bwd(_ptr(pred), _ptr(target), pred.numel(), float(inv_numel), _ptr(loss_out),
+                                int(accumulate), _ptr(dpred), _ptr(reduce_scratch(pred.device)), _stream()),
+          'srx_mse_fwd_bwd')
+    return dpred
+
+
+def l2_loss(w, scale, loss_out, accumulate=True):
+    _chk(w, 'w')
+    check(lib().srx_l2_loss(_ptr(w), w.numel(), float(scale), _ptr(loss_out), int(accumulate),
+                            _ptr(reduce_scratch(w.device)), _stream()), 'srx_l2_loss')
+
+
+def adam_tf_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    for tns, n in ((w, 'w'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _chk(tns, n)
+    check(lib().srx_adam_tf_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), float(lr), float(beta1),
+                                 float(beta2), float(eps), int(t), float(grad_scale), _stream()), 'srx_adam_tf_step')
+
+
+def momentum_clip_step(w, g, acc, lr, momentum=0.9, cap=float('inf'), grad_scale=1.0):
+    for tns, n in ((w, 'w'), (g, 'g'), (acc, 'acc')):
+        _chk(tns, n)
+    cap = min(float(cap), 3.0e38)
+    check(lib().srx_momentum_clip_step(_ptr(w), _ptr(g), _ptr(acc), w.numel(), float(lr), float(momentum), cap,
+                                       float(grad_scale), _stream()), 'srx_momentum_clip_step')
+
+
+def psnr(a, b, max_val):
+    _chk(a, 'a'); _chk(b, 'b')
+    N = a.shape[0]
+    out = torch.empty((N,), dtype=torch.float32, device=a.device)
+    check(lib().srx_psnr(_ptr(a), _ptr(b), _ptr(out), N, a.numel() // N, float(max_val), _stream()), 'srx_psnr')
+    return out
+
+
+def saturate_u8(x):
+    _chk(x, 'x')
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().srx_saturate_u8(_ptr(x), ctypes.c_void_p(out.data_ptr()), x.numel(), _stream()), 'srx_saturate_u8')
+    return out
+
+
+def affine(x, a, b, out=None):
+    _chk(x, 'x')
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_affine(_ptr(x), _ptr(out), x.numel(), float(a), float(b), _stream()), 'srx_affine')
+    return out
+
+
+def upsample_nearest(x, f):
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = torch.empty((N, H * f, W * f, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_upsample_nearest(_ptr(x), _ptr(out), N, H, W, C, f, _stream()), 'srx_upsample_nearest')
+    return out
