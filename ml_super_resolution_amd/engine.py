@@ -1,0 +1,244 @@
+"""
+engine.py -- the layer-stack engine behind the model mirrors.
+
+A `ConvStack` is what the reference's `build_model` functions describe: a chain of stride-1
+convolutions with bias + activation (vdsr/vdsr/model_vdsr.py:47-106,
+espcn/espcn/model_espcn.py:30-62, srcnn/srcnn.py:100-130), an MSE loss with optional L2
+regulariser (model_vdsr.py:120-125), and a TF-semantics Adam / Momentum+clip update
+(model_vdsr.py:145-184).  TensorFlow's autodiff is replaced by an explicit backward over the
+C-ABI ops: per layer one fused dgrad (+ upstream activation gradient) and one wgrad
+(+ bias grad + weight decay).
+
+Memory layout (sized for 288 GB HBM: everything stays resident):
+  * all kernels and biases live in ONE flat fp32 buffer (`params`), each tensor starting on a
+    16-byte boundary; gradients, Adam m/v (or momentum) mirror that layout, so the optimizer is
+    one launch and the data-parallel exchange is ONE all-reduce of `grads`;
+  * every layer's post-activation output is kept for backward (VDSR-20 @ 256x41x41: 2.1 GB);
+  * two ping-pong buffers hold the running pre-activation gradient.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+class LayerSpec(object):
+    """One conv layer.  `scope` is the TF variable scope (`conv2d`, `conv2d_1`, `f1`, ...):
+    variables are `<scope>/kernel` and `<scope>/bias`."""
+
+    def __init__(self, ksize, cin, cout, padding='same', act=None, scope=None):
+        self.kh, self.kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+        self.cin, self.cout = cin, cout
+        self.padding = padding.lower()
+        self.act = act
+        self.scope = scope
+
+    @property
+    def kernel_shape(self):
+        return (self.kh, self.kw, self.cin, self.cout)
+
+    def out_hw(self, h, w):
+        if self.padding == 'same':
+            return h, w
+        return h - self.kh + 1, w - self.kw + 1
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class ConvStack(object):
+    def __init__(self, specs, device='cuda', residual=False, weight_decay=0.0):
+        """residual: output = input + stack(input) (VDSR, model_vdsr.py:104).
+        weight_decay: scale of tf.contrib.layers.l2_regularizer on every kernel."""
+        self.specs = list(specs)
+        self.device = torch.device(device)
+        self.residual = residual
+        self.weight_decay = float(weight_decay)
+        # ---- flat parameter layout
+        self.slices = []          # per layer: (k_off, k_len, b_off, b_len)
+        off = 0
+        for s in self.specs:
+            kn = s.kh * s.kw * s.cin * s.cout
+            k_off = off
+            off = _align4(off + kn)
+            b_off = off
+            off = _align4(off + s.cout)
+            self.slices.append((k_off, kn, b_off, s.cout))
+        self.flat_size = off
+        self.num_params = sum(kn + bn for _, kn, _, bn in self.slices)
+        z = lambda: torch.zeros(self.flat_size, dtype=torch.float32, device=self.device)
+        self.params, self.grads = z(), z()
+        self.opt_m, self.opt_v = None, None     # Adam slots / momentum accumulator (lazy)
+        self.global_step = 0
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._acts = None
+        self._bufs = {}
+        self._ws = None
+        self.grad_hook = None      # called with the flat gradient after backward (DP all-reduce)
+
+    # ---- parameter views -------------------------------------------------------------------
+    def kernel(self, i, buf=None):
+        k_off, kn, _, _ = self.slices[i]
+        return (self.params if buf is None else buf)[k_off:k_off + kn].view(self.specs[i].kernel_shape)
+
+    def bias(self, i, buf=None):
+        _, _, b_off, bn = self.slices[i]
+        return (self.params if buf is None else buf)[b_off:b_off + bn]
+
+    def variables(self):
+        """{tf variable name: tensor view}, e.g. 'conv2d_3/kernel'."""
+        out = {}
+        for i, s in enumerate(self.specs):
+            scope = s.scope or ('layer%d' % i)
+            out[scope + '/kernel'] = self.kernel(i)
+            out[scope + '/bias'] = self.bias(i)
+        return out
+
+    def load_variables(self, values):
+        """values: {name: array-like}; names as in variables() (a trailing ':0' is accepted)."""
+        mine = self.variables()
+        for name, val in values.items():
+            key = name[:-2] if name.endswith(':0') else name
+            if key not in mine:
+                raise KeyError('unknown variable %r' % name)
+            t = torch.as_tensor(val, dtype=torch.float32)
+            if tuple(t.shape) != tuple(mine[key].shape):
+                raise ValueError('%s: shape %s != %s' % (name, tuple(t.shape), tuple(mine[key].shape)))
+            mine[key].copy_(t.to(self.device))
+
+    def set_params(self, pairs):
+        """pairs: [(kernel, bias)] per layer (numpy or torch)."""
+        for i, (k, b) in enumerate(pairs):
+            self.kernel(i).copy_(torch.as_tensor(k, dtype=torch.float32).to(self.device))
+            self.bias(i).copy_(torch.as_tensor(b, dtype=torch.float32).to(self.device))
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def _buf(self, key, shape):
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _shapes(self, x_shape):
+        n, h, w, _ = x_shape
+        shapes = []
+        for s in self.specs:
+            h, w = s.out_hw(h, w)
+            shapes.append((n, h, w, s.cout))
+        return shapes
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x, keep=True):
+        """Returns the stack output; with keep=True every layer's output is kept for backward()
+        and exposed through `self.acts` (acts[0] is the input, acts[i+1] layer i's output)."""
+        shapes = self._shapes(x.shape)
+        acts = [x]
+        t = x
+        last = len(self.specs) - 1
+        for i, s in enumerate(self.specs):
+            skip = x if (self.residual and i == last) else None
+            if keep:
+                out = self._buf(('act', i), shapes[i])
+            else:
+                out = self._buf(('tmp', i & 1, shapes[i]), shapes[i])
+            t = ops.conv2d_fwd(t, self.kernel(i), self.bias(i), s.padding, s.act, skip=skip, out=out)
+            acts.append(t)
+        self._acts = acts if keep else None
+        self.acts = acts
+        return t
+
+    # ---- loss + backward ----------------------------------------------------------------------
+    def loss_and_backward(self, target, numel_global=None):
+        """MSE(output, target) [+ weight decay terms] into self.loss (device scalar) and the full
+        gradient into self.grads.  With data parallelism pass nothing: every rank uses its LOCAL
+        mean and the hook averages the gradients (identical to the global mean for equal shards;
+        the regulariser gradient is the same on every rank, so averaging preserves it)."""
+        if self._acts is None:
+            raise RuntimeError('forward(keep=True) must run before loss_and_backward')
+        acts = self._acts
+        y = acts[-1]
+        last = len(self.specs) - 1
+        inv = 1.0 / (y.numel() if numel_global is None else numel_global)
+        dy = self._buf(('dy', 0), y.shape)
+        ops.mse_fwd_bwd(y, target, self.loss, inv_numel=inv, accumulate=False, dpred=dy)
+        if self.weight_decay:
+            for i in range(len(self.specs)):
+                ops.l2_loss(self.kernel(i), self.weight_decay, self.loss, accumulate=True)
+        if self.specs[last].act is not None:
+            dpre = ops.act_bwd(dy, y, self.specs[last].act, out=self._buf(('dpre_last',), y.shape))
+        else:
+            dpre = dy
+        if self._ws is None:
+            need = max(ops.bwd_filter_workspace_bytes(acts[i].shape, s.kernel_shape, s.padding)
+                       for i, s in enumerate(self.specs))
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        for i in range(last, -1, -1):
+            s = self.specs[i]
+            ops.conv2d_bwd_filter(acts[i], dpre, s.kernel_shape, s.padding,
+                                  w_for_decay=self.kernel(i) if self.weight_decay else None,
+                                  wd_scale=self.weight_decay, dw=self.kernel(i, self.grads),
+                                  dbias=self.bias(i, self.grads), workspace=self._ws)
+            if i > 0:
+                prev_act = self.specs[i - 1].act
+                dpre = ops.conv2d_bwd_data(dpre, self.kernel(i), acts[i].shape, s.padding,
+                                           x_in=acts[i] if prev_act is not None else None, in_act=prev_act,
+                                           out=self._buf(('dx', i & 1, acts[i].shape), acts[i].shape))
+        if self.grad_hook is not None:
+            self.grad_hook(self.grads)
+        return self.loss
+
+    # ---- optimizers ---------------------------------------------------------------------------
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """tf.train.AdamOptimizer(...).minimize(loss, global_step)."""
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.params)
+            self.opt_v = torch.zeros_like(self.params)
+        self.global_step += 1
+        ops.adam_tf_step(self.params, self.grads, self.opt_m, self.opt_v, lr, self.global_step, beta1, beta2, eps)
+
+    def momentum_clip_step(self, lr, momentum=0.9, gradient_cap=0.01):
+        """model_vdsr.py:158-184: clip every gradient element to +-gradient_cap/lr, then Momentum."""
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.params)
+        self.global_step += 1
+        ops.momentum_clip_step(self.params, self.grads, self.opt_m, lr, momentum, gradient_cap / lr)
+
+    # ---- checkpoint (own format, TF variable names) -----------------------------------------
+    def state_dict(self):
+        sd = {'global_step': self.global_step, 'params': self.params.detach().cpu()}
+        if self.opt_m is not None:
+            sd['opt_m'] = self.opt_m.detach().cpu()
+        if self.opt_v is not None:
+            sd['opt_v'] = self.opt_v.detach().cpu()
+        return sd
+
+    def load_state_dict(self, sd):
+        self.params.copy_(sd['params'].to(self.device))
+        self.global_step = int(sd['global_step'])
+        if 'opt_m' in sd:
+            self.opt_m = sd['opt_m'].to(self.device).clone()
+        if 'opt_v' in sd:
+            self.opt_v = sd['opt_v'].to(self.device).clone()
+
+
+# ---- initialisers (the reference's; TF's RNG stream itself cannot be reproduced) --------------
+def xavier_uniform_(t, generator=None):
+    """tf.contrib.layers.xavier_initializer(): U(+-sqrt(6/(fan_in+fan_out))), fan = kh*kw*C.
+    vdsr/vdsr/model_vdsr.py:27."""
+    kh, kw, cin, cout = t.shape
+    lim = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    t.copy_((torch.rand(t.shape, generator=generator) * 2 - 1).mul_(lim).to(t.device))
+
+
+def truncated_normal_(t, stddev, generator=None):
+    """tf.truncated_normal_initializer(stddev): redraw beyond 2 sigma.
+    espcn/espcn/model_espcn.py:21, srcnn/srcnn.py:84."""
+    v = torch.randn(t.shape, generator=generator)
+    bad = v.abs() > 2
+    while bad.any():
+        v[bad] = torch.randn(int(bad.sum()), generator=generator)
+        bad = v.abs() > 2
+    t.copy_(v.mul_(stddev).to(t.device))
