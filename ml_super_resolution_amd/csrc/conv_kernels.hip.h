@@ -39,18 +39,22 @@ struct ConvArgs {
     int units_total;      // N*NTX*OH
     int act, post_relu, mask_act;
     float inv_rs;         // 1/RS
+    int stagger;          // s_sleep(127) count for the second resident workgroup (0 = off)
+    int dbg;              // diagnostic timing knobs (SRX_DBG): 1 = stage only the first tile, 2 = no stores
+    unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
 };
 
 struct WgradArgs {
     const float* x;     // layer input [N,H,W,Cin]
     const float* dpre;  // gradient wrt pre-activation output [N,OH,OW,Cout]
-    float* part_dw;     // [G][KH*KW*Cin*Cout]
-    float* part_db;     // [G][Cout]
+    float* part;        // [G][part_stride]: KH*KW*Cin*Cout floats of dW then Cout floats of dbias
+    int part_stride;
     int N, H, W, OH, OW, Cin, Cout;
     int pad_t, pad_l;
     int TH, TW, NTX, RS;
     int units_total;
     float inv_rs;
+    int stagger;
 };
 
 template <int CINP>
@@ -87,8 +91,34 @@ __device__ __forceinline__ int fdiv_small(int s, float inv_d, int d) {
     return q;
 }
 
+#ifdef SRX_TRACE
+#define SRX_STAMP() __builtin_amdgcn_s_memtime()
+#else
+#define SRX_STAMP() 0ull
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// make every tile boundary wait for the previous tile's output stores to retire.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Two workgroups share a CU.  Launched together they would stage their tiles at the same time and
+// leave the MFMA pipe idle; delaying the one whose waves sit in odd hardware wave slots by about
+// half a tile keeps one of them computing while the other stages.  Pure scheduling hint: results
+// never depend on it (each wave decides for itself; the first barrier re-joins the workgroup).
+__device__ __forceinline__ void stagger_second_workgroup(int sleeps) {
+    // HW_REG_HW_ID (id 4), bits [3:0] = wave slot on the SIMD
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (slot & 1) {
+        for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 // Stage one tile's input halo into LDS.  Slot s <-> (r = s / RS, c = s % RS) <-> input pixel
 // (h_in0 + r, w_in0 + c); out-of-image slots are written as zeros (TF SAME zero padding).
+// Written to cost few VALU instructions: branch-free, 32-bit offsets inside the image, loads
+// always issued (clamped to the image base) and zeroed by a select, NB loads in flight.
 template <int CINP>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, int n, int H, int W,
                                            int Cin, int h_in0, int w_in0, int RS, float inv_rs,
@@ -96,134 +126,258 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
     constexpr int PS = Lds<CINP>::PS;
     constexpr int TPP = CINP / 4;    // threads per pixel (each moves 16 B)
     constexpr int PPP = 256 / TPP;   // pixels per pass
+    constexpr int NB = 8;            // 16-B loads in flight per thread
     const int c4 = tid % TPP;
     const int sp = tid / TPP;
-    const bool vec = (Cin & 3) == 0;
-    const float* xn = x + (size_t)n * H * W * Cin;
-    for (int s0 = 0; s0 < n_need; s0 += 4 * PPP) {
-        f32x4 v[4];
-        int sl[4];
+    const float* xn = x + (size_t)n * H * W * Cin;      // wave-uniform base; offsets below fit 32 bits
+    const bool ch_ok = 4 * c4 < Cin;
+    if ((Cin & 3) == 0) {
+        for (int s0 = sp; s0 < n_need; s0 += NB * PPP) {
+            f32x4 v[NB];
+            bool ok[NB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int s = s0 + j * PPP + sp;
-            sl[j] = s;
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s < n_need) {
+            for (int j = 0; j < NB; ++j) {
+                const int s = s0 + j * PPP;
                 const int r = fdiv_small(s, inv_rs, RS);
                 const int c = s - r * RS;
                 const int ih = h_in0 + r, iw = w_in0 + c;
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-                    const float* p = xn + ((size_t)ih * W + iw) * Cin + 4 * c4;
-                    if (vec) {
-                        if (4 * c4 < Cin) v[j] = *reinterpret_cast<const f32x4*>(p);
-                    } else {
+                ok[j] = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W) & (s < n_need) & ch_ok;
+                const unsigned off = ok[j] ? (unsigned)((ih * W + iw) * Cin + 4 * c4) : 0u;
+                v[j] = *reinterpret_cast<const f32x4*>(xn + off);
+            }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (4 * c4 + e < Cin) v[j][e] = p[e];
-                    }
-                }
+            for (int j = 0; j < NB; ++j) {
+                const int s = s0 + j * PPP;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (s < n_need) *reinterpret_cast<f32x4*>(lds + s * PS + 4 * c4) = ok[j] ? v[j] : z;
             }
         }
+    } else {
+        // channel counts that are not a multiple of 4 (RGB inputs, 27-channel sub-pixel tensors)
+        for (int s = sp; s < n_need; s += PPP) {
+            const int r = fdiv_small(s, inv_rs, RS);
+            const int c = s - r * RS;
+            const int ih = h_in0 + r, iw = w_in0 + c;
+            const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (sl[j] < n_need) *reinterpret_cast<f32x4*>(lds + (size_t)sl[j] * PS + 4 * c4) = v[j];
+            for (int e = 0; e < 4; ++e) {
+                const bool oke = ok & (4 * c4 + e < Cin);
+                const float t = xn[oke ? (unsigned)((ih * W + iw) * Cin + 4 * c4 + e) : 0u];
+                v[e] = oke ? t : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(lds + s * PS + 4 * c4) = v;
+        }
     }
 }
 
 // Epilogue shared by all forward / dgrad variants: lane holds channels cb..cb+3 of pixel (orow, ocol).
-template <int G>
-__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const bool (&valid)[G], const int (&orow)[G],
-                                              const int (&ocol)[G], const ConvArgs& a, int n, int h, int ow0, int kq,
-                                              int cout0) {
-    // ---- epilogue: lane holds channels cb..cb+3 of pixel (orow, ocol)
-    const int cb = cout0 + 4 * kq;
-    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+// The skip / mask operand (the API never passes both) is fetched BEFORE the MFMA loop by
+// conv_prefetch_aux so its latency hides behind the matrix work.  Offsets are 32-bit element
+// offsets from the image's base (the host rejects images of 2^31 elements or more).
+// AUX (template): the launch has a skip or mask operand.  It is a compile-time property because a
+// conditional load in the epilogue makes hipcc's wait-count bookkeeping assume the load may be
+// pending, and the counted s_waitcnt it inserts then waits for the group's own output STORES.
+template <int G, bool AUX>
+__device__ __forceinline__ void conv_prefetch_aux(f32x4 (&aux)[G], const unsigned (&off)[G], const ConvArgs& a,
+                                                  size_t img_base, bool vec) {
+    const float* src = a.mask ? a.mask : a.skip;
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
-        if (!valid[i] || cb >= a.Cout) continue;
-        const size_t off = (((size_t)n * a.OH + h + orow[i]) * a.OW + ow0 + ocol[i]) * a.Cout + cb;
-        f32x4 v = acc[i];
+    for (int i = 0; i < G; ++i) aux[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (AUX && vec) {
+        src += img_base;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-        if (vec) {
-            if (a.skip) {
-                const f32x4 s = *reinterpret_cast<const f32x4*>(a.skip + off);
-                v += s;
+        for (int i = 0; i < G; ++i) aux[i] = *reinterpret_cast<const f32x4*>(src + off[i]);
+    }
+}
+
+// Branch-free forms for the piecewise-linear activations (none / relu / leaky-relu):
+//   y = max(v, slope * v),  dy/dv seen through y: (y > 0) ? 1 : slope     with slope = 1, 0, 0.2
+// tanh / sigmoid take one wave-uniform branch per accumulator.
+__device__ __forceinline__ float act_slope(int act) {
+    return act == ACT_RELU ? 0.0f : (act == ACT_LRELU ? 0.2f : 1.0f);
+}
+
+__device__ __forceinline__ f32x4 act_apply4(f32x4 v, int act, float slope) {
+    if (act == ACT_TANH || act == ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x4 act_grad4(f32x4 v, f32x4 m, int act, float slope) {
+    if (act == ACT_TANH || act == ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= (act == ACT_TANH) ? (1.0f - m[e] * m[e]) : m[e] * (1.0f - m[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : slope * v[e];
+    }
+    return v;
+}
+
+template <int G, bool AUX>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4 (&aux)[G], const bool (&valid)[G],
+                                              const unsigned (&off)[G], const ConvArgs& a, size_t img_base, int cb,
+                                              bool vec) {
+    float* yb = a.y + img_base;
+    const float slope = act_slope(a.act), mslope = act_slope(a.mask_act);
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            f32x4 v = act_apply4(acc[i], a.act, slope);
+            if (AUX) {
+                if (a.skip) v += aux[i];
+                if (a.post_relu) v = act_apply4(v, ACT_RELU, 0.0f);
+                if (a.mask) v = act_grad4(v, aux[i], a.mask_act, mslope);
             }
-            if (a.post_relu) {
+            if ((a.dbg & 2) && v[0] != 12345.678f) continue;
+            if (valid[i]) *reinterpret_cast<f32x4*>(yb + off[i]) = v;
+        }
+    } else {
+        // ragged channel counts (Cout = 3, 27, ...): scalar tail
+        const float* sk = (AUX && a.skip) ? a.skip + img_base : nullptr;
+        const float* mk = (AUX && a.mask) ? a.mask + img_base : nullptr;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (a.mask) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + off);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_y(m[e], a.mask_act);
-            }
-            *reinterpret_cast<f32x4*>(a.y + off) = v;
-        } else {
+        for (int i = 0; i < G; ++i) {
+            if (!valid[i]) continue;
+            const f32x4 v = act_apply4(acc[i], a.act, slope);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (cb + e < a.Cout) {
                     float t = v[e];
-                    if (a.skip) t += a.skip[off + e];
-                    if (a.post_relu) t = fmaxf(t, 0.f);
-                    if (a.mask) t *= act_grad_from_y(a.mask[off + e], a.mask_act);
-                    a.y[off + e] = t;
+                    if (sk) t += sk[off[i] + e];
+                    if (AUX && a.post_relu) t = fmaxf(t, 0.f);
+                    if (mk) t *= act_grad_from_y(mk[off[i] + e], a.mask_act);
+                    yb[off[i] + e] = t;
                 }
             }
         }
     }
+}
+
+#define SRX_MFMA(ACC, A, B) "v_mfma_f32_16x16x4_f32 %" #ACC ", %" #A ", %" #B ", %" #ACC "\n\t"
+
+// GUARD: the kernel is built with > 256 registers, so operands may reach the block through a
+// v_accvgpr_read (a VALU write) that needs wait states before an MFMA reads it.
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block(f32x4 (&c)[1], float w0, float w1, float w2, float w3, const f32x4 (&b)[1]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 1, 5) SRX_MFMA(0, 2, 6) SRX_MFMA(0, 3, 7) SRX_MFMA(0, 4, 8)
+                     : "+v"(c[0])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]));
+    else
+        asm volatile(SRX_MFMA(0, 1, 5) SRX_MFMA(0, 2, 6) SRX_MFMA(0, 3, 7) SRX_MFMA(0, 4, 8)
+                     : "+v"(c[0])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]));
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block(f32x4 (&c)[2], float w0, float w1, float w2, float w3, const f32x4 (&b)[2]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 2, 6) SRX_MFMA(1, 2, 10) SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13)
+                     : "+v"(c[0]), "+v"(c[1])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]));
+    else
+        asm volatile(SRX_MFMA(0, 2, 6) SRX_MFMA(1, 2, 10) SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13)
+                     : "+v"(c[0]), "+v"(c[1])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]));
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block(f32x4 (&c)[3], float w0, float w1, float w2, float w3, const f32x4 (&b)[3]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(2, 3, 15) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]));
+    else
+        asm volatile(SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(2, 3, 15) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]));
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block(f32x4 (&c)[4], float w0, float w1, float w2, float w3, const f32x4 (&b)[4]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(3, 4, 20) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(3, 5, 21) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18) SRX_MFMA(3, 6, 22) SRX_MFMA(0, 7, 11) SRX_MFMA(1, 7, 15) SRX_MFMA(2, 7, 19) SRX_MFMA(3, 7, 23)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]), "v"(b[3][0]), "v"(b[3][1]), "v"(b[3][2]), "v"(b[3][3]));
+    else
+        asm volatile(SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(3, 4, 20) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(3, 5, 21) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18) SRX_MFMA(3, 6, 22) SRX_MFMA(0, 7, 11) SRX_MFMA(1, 7, 15) SRX_MFMA(2, 7, 19) SRX_MFMA(3, 7, 23)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                     : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]), "v"(b[3][0]), "v"(b[3][1]), "v"(b[3][2]), "v"(b[3][3]));
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CINP, int G>
+template <int KH, int KW, int CINP, int G, bool GUARD, bool AUX>
 __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[KH * KW * (CINP / 4)],
                                            const f32x4 bias4, const ConvArgs& a, int n, int h, int ow0,
                                            int th, int tw, float inv_tw, int m_first, int m_step,
-                                           int li, int kq, int cout0) {
+                                           int li, int kq, int cout0, unsigned long long& t_mfma, unsigned long long& t_pro,
+                                           unsigned long long& t_epi) {
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = (CINP >= 16) ? CINP / 16 : 1;
+    const unsigned long long ts_pro = SRX_STAMP();
     const int npx = th * tw;
-    int laddr[G];   // float index of this lane's pixel (tap 0,0) in LDS
-    int orow[G], ocol[G];
+    const int cb = cout0 + 4 * kq;
+    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+    const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;   // wave-uniform
+    int laddr[G];       // float index of this lane's pixel (tap 0,0) in LDS
+    unsigned off[G];    // element offset of this lane's 4 output channels inside image n
     bool valid[G];
     f32x4 acc[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m_first + i * m_step) + li;
-        valid[i] = t < npx;
-        const int tt = valid[i] ? t : 0;
-        orow[i] = fdiv_small(tt, inv_tw, tw);
-        ocol[i] = tt - orow[i] * tw;
-        laddr[i] = (orow[i] * a.RS + ocol[i]) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        valid[i] = (t < npx) & (cb < a.Cout);
+        const int tt = (t < npx) ? t : 0;
+        const int orow = fdiv_small(tt, inv_tw, tw);
+        const int ocol = tt - orow * tw;
+        laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        off[i] = valid[i] ? (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb) : 0u;
         acc[i] = bias4;
     }
+    f32x4 aux[G];
+    conv_prefetch_aux<G, AUX>(aux, off, a, img_base, vec);
     const int row_stride = a.RS * PS;
+    if constexpr (CINP >= 16) {
+        // Software pipeline over the KH*KW*NG k-groups: the LDS fragments of group t+1 are requested
+        // before the MFMAs of group t are issued.
+        constexpr int NBLK = KH * KW * NG;
+        // accumulators were initialised by VALU moves: keep the first MFMA clear of that write
+        asm volatile("s_nop 1" ::: "memory");
+        const unsigned long long ts0 = SRX_STAMP();
+        t_pro += ts0 - ts_pro;
+        f32x4 cur[G], nxt[G];
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
+        for (int i = 0; i < G; ++i) cur[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i]);
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int tap = kh * KW + kw;
-            if constexpr (CINP >= 16) {
+        for (int t = 0; t < NBLK; ++t) {
+            if (t + 1 < NBLK) {
+                const int t1 = t + 1;
+                const int kh1 = (t1 / NG) / KW, kw1 = (t1 / NG) % KW, g1 = t1 % NG;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    f32x4 av[G];
+                for (int i = 0; i < G; ++i)
+                    nxt[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i] + kh1 * row_stride + kw1 * PS + 16 * g1);
+            }
+            const int tap = t / NG, g = t % NG;
+            const int wb = tap * (CINP / 4) + 4 * g;
+            mfma_block<GUARD>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
 #pragma unroll
-                    for (int i = 0; i < G; ++i)
-                        av[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i] + kh * row_stride + kw * PS + 16 * g);
+            for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+        }
+        // MFMA results are read by VALU code next: software must cover the result latency
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        t_mfma += SRX_STAMP() - ts0;
+    } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
+        for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-                        for (int i = 0; i < G; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap * (CINP / 4) + 4 * g + s], av[i][s],
-                                                                          acc[i], 0, 0, 0);
-                    }
-                }
-            } else {
+            for (int kw = 0; kw < KW; ++kw) {
+                const int tap = kh * KW + kw;
                 float av[G];
 #pragma unroll
                 for (int i = 0; i < G; ++i) av[i] = lds[laddr[i] + kh * row_stride + kw * PS];
@@ -233,13 +387,15 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
             }
         }
     }
-    conv_epilogue<G>(acc, valid, orow, ocol, a, n, h, ow0, kq, cout0);
+    const unsigned long long ts_epi = SRX_STAMP();
+    conv_epilogue<G, AUX>(acc, aux, valid, off, a, img_base, cb, vec);
+    t_epi += SRX_STAMP() - ts_epi;
 }
 
 // KH,KW: filter; CINP: padded input channels held per LDS pixel (4, 32 or 64); NCH: number of
 // 16-wide output-channel chunks (1, 2 or 4 -> 4/NCH waves share the pixels of a chunk);
 // WT: read the filters transposed + flipped (dgrad); MINW: waves per SIMD for launch bounds.
-template <int KH, int KW, int CINP, int NCH, bool WT, int MINW>
+template <int KH, int KW, int CINP, int NCH, bool WT, int MINW, bool AUX>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TAPS = KH * KW;
@@ -251,24 +407,26 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     const int li = lane & 15, kq = lane >> 4;
     const int chunk = wave % NCH, part = wave / NCH;
     const int cout0 = chunk * 16;
+#ifdef SRX_TRACE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- stationary weights: wr[tap][j], k index of lane = channel ci(j, kq)
     float wr[TAPS * KSPT];
     {
+        // branch-free: out-of-range (padded) channels read element 0 and are zeroed by a select
         const int co = cout0 + li;
+        const bool co_ok = co < a.Cout;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
             for (int j = 0; j < KSPT; ++j) {
                 const int ci = (CINP >= 16) ? 16 * (j / 4) + 4 * kq + (j % 4) : kq;
-                float v = 0.f;
-                if (ci < a.Cin && co < a.Cout) {
-                    if (!WT)
-                        v = a.w[((size_t)tap * a.Cin + ci) * a.Cout + co];
-                    else
-                        v = a.w[((size_t)(TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci];
-                }
-                wr[tap * KSPT + j] = v;
+                const bool ok = co_ok & (ci < a.Cin);
+                const unsigned idx = !WT ? (unsigned)((tap * a.Cin + ci) * a.Cout + co)
+                                         : (unsigned)(((TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci);
+                const float v = a.w[ok ? idx : 0u];
+                wr[tap * KSPT + j] = ok ? v : 0.f;
             }
         }
     }
@@ -282,6 +440,9 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     const long G_ = gridDim.x;
     const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
     const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    if (a.stagger) stagger_second_workgroup(a.stagger);
+    unsigned long long t_mfma = 0, t_stage = 0, t_bar1 = 0, t_load = 0, t_pro = 0, t_epi = 0;
+    const unsigned long long t_begin = SRX_STAMP();
     int u = u0;
     while (u < u1) {
         const int h = u % a.OH;
@@ -295,31 +456,51 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
         const int n_need = (th + KH - 1) * a.RS + (KW - 1);
 
-        __syncthreads();
-        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
-        __syncthreads();
+        const unsigned long long ts_stage = SRX_STAMP();
+        lds_barrier();
+        const unsigned long long ts_b1 = SRX_STAMP();
+        if (!(a.dbg & 1) || u == u0)
+            stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
+        const unsigned long long ts_ld = SRX_STAMP();
+        lds_barrier();
+        t_stage += SRX_STAMP() - ts_stage;
+        t_bar1 += ts_b1 - ts_stage;
+        t_load += ts_ld - ts_b1;
 
         const int n_sub = (th * tw + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;  // subtiles of this wave
         const float inv_tw = 1.0f / (float)tw;
         if (cnt > 0) {
-            const int ng = (cnt + 3) >> 2;
+            // instances with an aux operand also hold its prefetched registers: 3 accumulators per group
+            constexpr int MAXG = AUX ? 3 : 4;
+            const int ng = (cnt + MAXG - 1) / MAXG;
             const int base = cnt / ng, rem = cnt % ng;
             int idx = 0;
             for (int gi = 0; gi < ng; ++gi) {
                 const int gs = base + (gi < rem ? 1 : 0);
                 const int m_first = part + idx * NPART;
-                switch (gs) {
-                    case 4: conv_group<KH, KW, CINP, 4>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0); break;
-                    case 3: conv_group<KH, KW, CINP, 3>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0); break;
-                    case 2: conv_group<KH, KW, CINP, 2>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0); break;
-                    default: conv_group<KH, KW, CINP, 1>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0); break;
-                }
+                if (MAXG >= 4 && gs == 4)
+                    conv_group<KH, KW, CINP, (MAXG >= 4 ? 4 : 1), (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
+                else if (gs == 3)
+                    conv_group<KH, KW, CINP, 3, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
+                else if (gs == 2)
+                    conv_group<KH, KW, CINP, 2, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
+                else
+                    conv_group<KH, KW, CINP, 1, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
                 idx += gs;
             }
         }
         u += th;
     }
+#ifdef SRX_TRACE
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        tr[8] = t_bar1; tr[9] = t_load; tr[10] = t_pro; tr[11] = t_epi;
+        tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_mfma; tr[3] = t_stage;
+        tr[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);   // HW_ID[15:0]
+        tr[5] = rt_entry; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = t_entry;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,21 +514,28 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
                                                    int m_first, int m_step, int li, int kq, int cout0) {
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = (CINP >= 16) ? CINP / 16 : 1;
-    const int npx = th * tw;
     const int TAPS = KH * KW;
-    int laddr[G], orow[G], ocol[G];
+    const int npx = th * tw;
+    const int cb = cout0 + 4 * kq;
+    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+    const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;   // wave-uniform
+    int laddr[G];       // float index of this lane's pixel (tap 0,0) in LDS
+    unsigned off[G];    // element offset of this lane's 4 output channels inside image n
     bool valid[G];
     f32x4 acc[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m_first + i * m_step) + li;
-        valid[i] = t < npx;
-        const int tt = valid[i] ? t : 0;
-        orow[i] = fdiv_small(tt, inv_tw, tw);
-        ocol[i] = tt - orow[i] * tw;
-        laddr[i] = (orow[i] * a.RS + ocol[i]) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        valid[i] = (t < npx) & (cb < a.Cout);
+        const int tt = (t < npx) ? t : 0;
+        const int orow = fdiv_small(tt, inv_tw, tw);
+        const int ocol = tt - orow * tw;
+        laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        off[i] = valid[i] ? (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb) : 0u;
         acc[i] = bias4;
     }
+    f32x4 aux[G];
+    conv_prefetch_aux<G, true>(aux, off, a, img_base, vec);
     const int row_stride = a.RS * PS;
     const int co = cout0 + li;
     const bool co_ok = co < a.Cout;
@@ -384,7 +572,7 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
             }
         }
     }
-    conv_epilogue<G>(acc, valid, orow, ocol, a, n, h, ow0, kq, cout0);
+    conv_epilogue<G, true>(acc, aux, valid, off, a, img_base, cb, vec);
 }
 
 template <int CINP, int NCH, bool WT>
@@ -406,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_generic_kernel(const ConvArg
     const long G_ = gridDim.x;
     const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
     const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    if (a.stagger) stagger_second_workgroup(a.stagger);
     int u = u0;
     while (u < u1) {
         const int h = u % a.OH;
@@ -481,6 +670,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
     const long G_ = gridDim.x;
     const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
     const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    if (a.stagger) stagger_second_workgroup(a.stagger);
     int u = u0;
     while (u < u1) {
         const int h = u % a.OH;
@@ -548,7 +738,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
     }
 
     // ---- write this workgroup's partial
-    float* pw = a.part_dw + (size_t)blockIdx.x * TAPS * a.Cin * a.Cout;
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
     for (int k = 0; k < QW; ++k) {
         const int q = qpart + k * NQP;
@@ -563,11 +753,9 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
             }
         }
     }
-    if (a.part_db) {
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (qpart == 0 && kq == 0 && co_ok) a.part_db[(size_t)blockIdx.x * a.Cout + co] = bsum;
-    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
 }
 
 }  // namespace srx

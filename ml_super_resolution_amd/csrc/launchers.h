@@ -18,7 +18,8 @@ bool launch_conv_misc(const ConvKey& k, const ConvArgs& a, int grid, size_t lds,
 bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 
-hipError_t launch_reduce_partials(const float* part, int G, size_t n, float* out, const float* w, float wd, hipStream_t s);
+hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
+                                  const float* w, float wd, hipStream_t s);
 
 template <typename K, typename A>
 inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hipStream_t s) {
@@ -32,7 +33,10 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
 
 #define SRX_CONV_CASE(KH, KW, CINP, NCH, WT, MINW)                                                        \
     if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt == WT) {                       \
-        *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW>, a, grid, lds, s);           \
+        if (a.skip || a.mask)                                                                             \
+            *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW, true>, a, grid, lds, s); \
+        else                                                                                              \
+            *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW, false>, a, grid, lds, s);\
         return true;                                                                                      \
     }
 #define SRX_WGRAD_CASE(KH, KW, CINP, NCH, MINW)                                                           \

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/srx.h"
@@ -85,6 +86,11 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     long g = rows_total / p->TH;
     if (g < 1) g = 1;
     p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
+    {
+        static int genv = -2;
+        if (genv == -2) { const char* e = getenv("SRX_GRID"); genv = e ? atoi(e) : -1; }
+        if (genv > 0 && genv < p->grid) p->grid = genv;
+    }
     p->lds_bytes = ((size_t)(p->TH + KH - 1) * RS + (KW - 1)) * slot_bytes;
     return SRX_OK;
 }
@@ -99,8 +105,10 @@ int check_desc(const srx_conv_desc* d) {
     if (d->precision != 0) return fail(SRX_ERR_UNSUPPORTED, "precision mode %d not implemented", d->precision);
     if (d->pad_mode == SRX_PAD_VALID && (d->H < d->KH || d->W < d->KW))
         return fail(SRX_ERR_BAD_ARG, "VALID convolution with input smaller than the filter");
-    if ((long)d->N * d->H * d->W * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1L << 31) * 4)
-        return fail(SRX_ERR_UNSUPPORTED, "tensor too large for 32-bit unit indexing");
+    if ((long)d->H * d->W * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1L << 31))
+        return fail(SRX_ERR_UNSUPPORTED, "one image has >= 2^31 elements: beyond the kernels' 32-bit in-image offsets");
+    if ((long)d->N * d->H * 64 >= (1L << 31))
+        return fail(SRX_ERR_UNSUPPORTED, "too many rows for 32-bit unit indexing");
     return SRX_OK;
 }
 
@@ -110,6 +118,11 @@ void geometry(const srx_conv_desc* d, int* pad_t, int* pad_l, int* OH, int* OW) 
     } else {
         *pad_t = 0; *pad_l = 0; *OH = d->H - d->KH + 1; *OW = d->W - d->KW + 1;
     }
+}
+
+size_t part_stride(const srx_conv_desc* d) {
+    const size_t per = (size_t)d->KH * d->KW * d->Cin * d->Cout + (size_t)d->Cout;
+    return (per + 3) / 4 * 4;
 }
 
 int dispatch_conv(const Plan& p, bool wt, const ConvArgs& a, hipStream_t s) {
@@ -127,12 +140,32 @@ int dispatch_conv(const Plan& p, bool wt, const ConvArgs& a, hipStream_t s) {
     return SRX_OK;
 }
 
+// s_sleep(127) iterations (~3.4 us each) by which the second workgroup of a CU is delayed; only
+// worth it when every CU really hosts two long-running workgroups.  SRX_STAGGER overrides.
+int stagger_sleeps(const Plan& p) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("SRX_STAGGER");
+        env = e ? atoi(e) : -1;
+    }
+    if (env >= 0) return env;
+    if (p.grid < kMaxGrid) return 0;
+    const long tiles_per_wg = (long)p.units_total / ((long)p.grid * p.TH);
+    return tiles_per_wg >= 2 ? 4 : 0;
+}
+
 void fill_conv_args(ConvArgs* a, const Plan& p, int N, int H, int W, int in_c, int out_c) {
     a->N = N; a->H = H; a->W = W; a->OH = p.OH; a->OW = p.OW; a->Cin = in_c; a->Cout = out_c;
     a->pad_t = p.pad_t; a->pad_l = p.pad_l;
     a->TH = p.TH; a->TW = p.TW; a->NTX = p.NTX; a->RS = p.RS;
     a->units_total = p.units_total;
     a->inv_rs = 1.0f / (float)p.RS;
+    a->stagger = stagger_sleeps(p);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("SRX_DBG"); dbg = e ? atoi(e) : 0; }
+    a->dbg = dbg;
+    const char* tp = getenv("SRX_TRACE_PTR");   // diagnostic builds only
+    a->trace = tp ? (unsigned long long*)strtoull(tp, nullptr, 0) : nullptr;
 }
 
 }  // namespace
@@ -150,8 +183,7 @@ size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op) {
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
     if (make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p) != SRX_OK) return 0;
-    const size_t per = (size_t)d->KH * d->KW * d->Cin * d->Cout + (size_t)d->Cout;
-    return (size_t)p.grid * per * sizeof(float);
+    return (size_t)p.grid * part_stride(d) * sizeof(float);
 }
 
 int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const float* bias, const float* skip,
@@ -210,18 +242,19 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
     if (rc) return rc;
     const size_t wn = (size_t)d->KH * d->KW * d->Cin * d->Cout;
-    const size_t need = (size_t)p.grid * (wn + (size_t)d->Cout) * sizeof(float);
+    const size_t need = (size_t)p.grid * part_stride(d) * sizeof(float);
     if (!ws || ws_bytes < need)
         return fail(SRX_ERR_WORKSPACE, "bwd_filter needs %zu workspace bytes, got %zu", need, ws_bytes);
     if (!aligned16(ws)) return fail(SRX_ERR_ALIGN, "workspace must be 16-byte aligned");
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.dpre = dpre;
-    a.part_dw = (float*)ws;
-    a.part_db = (float*)ws + (size_t)p.grid * wn;
+    a.part = (float*)ws;
+    a.part_stride = (int)part_stride(d);
     a.N = d->N; a.H = d->H; a.W = d->W; a.OH = OH; a.OW = OW; a.Cin = d->Cin; a.Cout = d->Cout;
     a.pad_t = pt; a.pad_l = pl; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
+    a.stagger = stagger_sleeps(p);
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
@@ -229,9 +262,7 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
                     p.nch);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
-    err = launch_reduce_partials(a.part_dw, p.grid, wn, dw, w_for_decay, wd_scale, s);
-    if (err == hipSuccess && dbias)
-        err = launch_reduce_partials(a.part_db, p.grid, (size_t)d->Cout, dbias, nullptr, 0.f, s);
+    err = launch_reduce_partials(a.part, p.grid, a.part_stride, (int)wn, d->Cout, dw, dbias, w_for_decay, wd_scale, s);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "reduce launch failed: %s", hipGetErrorString(err));
     return SRX_OK;
 }

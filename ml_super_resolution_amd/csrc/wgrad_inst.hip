@@ -1,28 +1,44 @@
 // Conv2DBackpropFilter instances.
 #include "launchers.h"
 namespace srx {
-// out[j] = sum_g part[g][j] (+ wd * w[j]); fixed summation order -> deterministic.
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int G, size_t n, float* __restrict__ out,
-                                       const float* __restrict__ w, float wd) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-        s0 += part[(size_t)g * n + j];
-        s1 += part[(size_t)(g + 1) * n + j];
-        s2 += part[(size_t)(g + 2) * n + j];
-        s3 += part[(size_t)(g + 3) * n + j];
+// out = sum over the G per-workgroup partials, in a fixed order (deterministic):
+//   j <  wn : dw[j]      = sum_g part[g][j] (+ wd * w[j])
+//   j >= wn : dbias[j-wn] = sum_g part[g][j]
+// A block owns 64 consecutive outputs; its 256 threads are 16 float4 columns x 16 partial groups.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int G, int stride,
+                                                              int wn, int n, float* __restrict__ dw,
+                                                              float* __restrict__ dbias, const float* __restrict__ w,
+                                                              float wd) {
+    __shared__ f32x4 sh[16][17];
+    const int c = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 64 + 4 * c;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (j < n) {
+        const float* p = part + j;
+        for (int g = pg; g < G; g += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)g * stride);
     }
-    for (; g < G; ++g) s0 += part[(size_t)g * n + j];
-    float s = (s0 + s1) + (s2 + s3);
-    if (w) s += wd * w[j];
-    out[j] = s;
+    sh[pg][c] = s;
+    __syncthreads();
+    if (pg == 0 && j < n) {
+        f32x4 t = sh[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sh[k][c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = j + e;
+            if (jj < wn)
+                dw[jj] = t[e] + (w ? wd * w[jj] : 0.f);
+            else if (jj < wn + (n - wn) && dbias)
+                dbias[jj - wn] = t[e];
+        }
+    }
 }
 
-
-hipError_t launch_reduce_partials(const float* part, int G, size_t n, float* out, const float* w, float wd, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, G, n, out, w, wd);
+hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
+                                  const float* w, float wd, hipStream_t s) {
+    const int n = wn + cout;   // stride is a multiple of 4 >= n, so the float4 loads stay in the row
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, G, stride, wn, n,
+                       dw, dbias, w, wd);
     return hipGetLastError();
 }
 
