@@ -55,6 +55,7 @@ struct WgradArgs {
     int units_total;
     float inv_rs;
     int stagger;
+    int zero_slot;      // index of a pixel slot past the tile that the kernel keeps zeroed
 };
 
 template <int CINP>
@@ -347,8 +348,6 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
         // Software pipeline over the KH*KW*NG k-groups: the LDS fragments of group t+1 are requested
         // before the MFMAs of group t are issued.
         constexpr int NBLK = KH * KW * NG;
-        // accumulators were initialised by VALU moves: keep the first MFMA clear of that write
-        asm volatile("s_nop 1" ::: "memory");
         const unsigned long long ts0 = SRX_STAMP();
         t_pro += ts0 - ts_pro;
         f32x4 cur[G], nxt[G];
@@ -365,7 +364,12 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
             }
             const int tap = t / NG, g = t % NG;
             const int wb = tap * (CINP / 4) + 4 * g;
-            mfma_block<GUARD>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+            // the accumulators were initialised by VALU moves that the compiler may sink right in front
+            // of the first block: that block carries its own leading s_nop (as every GUARD block does)
+            if (t == 0)
+                mfma_block<true>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+            else
+                mfma_block<GUARD>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
 #pragma unroll
             for (int i = 0; i < G; ++i) cur[i] = nxt[i];
         }
@@ -607,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_generic_kernel(const ConvArg
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
         const int n_need = (th + KH - 1) * a.RS + (KW - 1);
-        __syncthreads();
+        lds_barrier();
         stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
-        __syncthreads();
+        lds_barrier();
         const int n_sub = (th * tw + 15) >> 4;
         const float inv_tw = 1.0f / (float)tw;
         for (int m = part; m < n_sub; m += 2 * NPART) {
@@ -627,6 +631,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_generic_kernel(const ConvArg
 // Rows of the (tap, ci) space are flattened as R = tap*CINP + ci; one b128 LDS read by lane (i, kq)
 // covers R = 64q + 4i + g (g = 0..3) for pixel kq of the step, feeding 4 MFMAs.
 // ---------------------------------------------------------------------------------------------
+// 4 MFMAs of one LDS fragment: acc[g] += x[g] (rows = input channels) * b (cols = output channels)
+__device__ __forceinline__ void mfma4_wgrad(f32x4 (&c)[4], const f32x4 x, float b) {
+    asm volatile(SRX_MFMA(0, 4, 8) SRX_MFMA(1, 5, 8) SRX_MFMA(2, 6, 8) SRX_MFMA(3, 7, 8)
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(b));
+}
+
+// per-lane cursor over the tile's pixels, 4 pixels per step (lane group kq takes pixel 4*step + kq)
+struct WgCursor {
+    int p;      // pixel index inside the tile
+    int c;      // its column
+    int xaddr;  // float index of its (tap 0,0) slot in LDS
+    int boff;   // element offset of dpre[pixel][0] from the tile's first pixel
+};
+
 template <int KH, int KW, int CINP, int NCH, int MINW>
 __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -635,8 +654,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
     constexpr int ROWS = TAPS * CINP;
     constexpr int Q = (ROWS + 63) / 64;
     constexpr int NQP = 4 / NCH;             // waves sharing a cout chunk split the q's
-    constexpr int QW = (Q + NQP - 1) / NQP;  // q's per wave
-    constexpr int PD = (QW >= 4) ? 2 : 8;    // dpre prefetch depth (steps)
+    constexpr int QW = (Q + NQP - 1) / NQP;  // q's (LDS fragments per step) of this wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -645,20 +663,21 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
     const int cout0 = chunk * 16;
     const int co = cout0 + li;
     const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;   // clamped: columns >= Cout are never written out
 
     // per-lane LDS offset (floats) of the tap/channel this lane feeds for each of its q's
     int toff[QW];
-    bool qok[QW];
 #pragma unroll
     for (int k = 0; k < QW; ++k) {
         const int q = qpart + k * NQP;
-        int R = 64 * q + 4 * li;  // first of the lane's 4 rows (all 4 share tap since CINP % 4 == 0)
-        qok[k] = (q < Q) && (R < ROWS);
-        if (!qok[k]) R = 0;
+        int R = 64 * q + 4 * li;  // first of the lane's 4 rows (all 4 share the tap since CINP % 4 == 0)
+        if (q >= Q || R >= ROWS) R = 0;
         const int tap = R / CINP, ci = R % CINP;
-        const int kh = tap / KW, kw = tap % KW;
-        toff[k] = (kh * a.RS + kw) * PS + ci;
+        toff[k] = ((tap / KW) * a.RS + (tap % KW)) * PS + ci;
     }
+    // one zeroed pixel slot after the tile: the operand of pixels beyond the tile's end
+    const int zaddr = a.zero_slot * PS + (4 * li) % CINP;
+    if (tid < PS) lds[a.zero_slot * PS + tid] = 0.f;
 
     f32x4 acc[QW][4];
 #pragma unroll
@@ -684,59 +703,74 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
         const int n_need = (th + KH - 1) * a.RS + (KW - 1);
 
-        __syncthreads();
+        lds_barrier();
         stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
-        __syncthreads();
+        lds_barrier();
 
         const int npx = th * tw;
         const int nsteps = (npx + 3) >> 2;
-        const float inv_tw = 1.0f / (float)tw;
-        const float* dbase = a.dpre + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout + co;
+        const float* dbase = a.dpre + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout + co_c;  // + 32-bit offsets
+        const int x_step = 4 * PS, x_wrap = (a.RS - tw) * PS;
+        const int b_step = 4 * a.Cout, b_wrap = (a.OW - tw) * a.Cout;
 
-        auto load_b = [&](int s) -> float {
-            const int p = 4 * s + kq;
-            float v = 0.f;
-            if (p < npx && co_ok) {
-                const int r = fdiv_small(p, inv_tw, tw);
-                const int c = p - r * tw;
-                v = dbase[((size_t)r * a.OW + c) * a.Cout];
-            }
-            return v;
+        auto advance = [&](WgCursor& cu) {
+            cu.p += 4; cu.c += 4; cu.xaddr += x_step; cu.boff += b_step;
+            while (cu.c >= tw) { cu.c -= tw; cu.xaddr += x_wrap; cu.boff += b_wrap; }   // once, unless tw < 4
         };
-        auto x_addr = [&](int s) -> int {
-            int p = 4 * s + kq;
-            if (p >= npx) p = npx - 1;  // finite data, multiplied by b = 0
-            const int r = fdiv_small(p, inv_tw, tw);
-            const int c = p - r * tw;
-            return (r * a.RS + c) * PS;
+        auto load_b = [&](const WgCursor& cu) -> float {
+            // always a valid address: pixels past the end re-read the tile's first pixel (their x operand is 0)
+            return dbase[cu.p < npx ? cu.boff : 0];
+        };
+        auto read_x = [&](const WgCursor& cu, int k) -> f32x4 {
+            return *reinterpret_cast<const f32x4*>(lds + (cu.p < npx ? cu.xaddr + toff[k] : zaddr));
         };
 
-        float bq[PD];
+        WgCursor cur;
+        {
+            const int r0 = fdiv_small(kq < npx ? kq : 0, 1.0f / (float)tw, tw);
+            cur.p = kq; cur.c = (kq < npx ? kq : 0) - r0 * tw;
+            cur.xaddr = (r0 * a.RS + cur.c) * PS; cur.boff = (r0 * a.OW + cur.c) * a.Cout;
+        }
+        WgCursor pf = cur;                      // dpre prefetch cursor, 3 steps ahead
+        float bq[3];
 #pragma unroll
-        for (int j = 0; j < PD; ++j) bq[j] = load_b(j);
+        for (int j = 0; j < 3; ++j) { bq[j] = load_b(pf); advance(pf); }
 
-        for (int s0 = 0; s0 < nsteps; s0 += PD) {
+        // ring of 3 LDS fragments running LA fragments ahead of the MFMAs, across step boundaries
+        // (fragment f of the stream = (step f / QW, k = f % QW); with one fragment per step the
+        // look-ahead is 1 so that only the next step's cursor is needed)
+        constexpr int LA = (QW >= 2) ? 2 : 1;
+        f32x4 ring[3];
+        WgCursor nxt = cur;
+        advance(nxt);
+        ring[0] = read_x(cur, 0);
+        if (LA == 2) ring[1] = read_x(cur, 1);
+
+        for (int s0 = 0; s0 < nsteps; s0 += 3) {
 #pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                const int s = s0 + j;
-                const float b = bq[j];
-                bq[j] = load_b(s + PD);
-                if (s < nsteps) {
-                    bsum += b;
-                    const int xa = x_addr(s);
+            for (int uu = 0; uu < 3; ++uu) {
+                if (s0 + uu < nsteps) {
+                    const float b = bq[uu];
+                    bq[uu] = load_b(pf);
+                    advance(pf);
+                    bsum += (cur.p < npx && co_ok) ? b : 0.f;
 #pragma unroll
                     for (int k = 0; k < QW; ++k) {
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(lds + xa + toff[k]);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[k][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], b, acc[k][g], 0, 0, 0);
+                        const int idx = (uu * QW + k) % 3;
+                        const int kk = k + LA;
+                        ring[(idx + LA) % 3] = (kk < QW) ? read_x(cur, kk) : read_x(nxt, kk - QW);
+                        mfma4_wgrad(acc[k], ring[idx], b);
                     }
+                    cur = nxt;
+                    advance(nxt);
                 }
             }
         }
         u += th;
     }
 
+    // MFMA results are read by VALU / stores next
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- write this workgroup's partial
     float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll

@@ -26,7 +26,7 @@ int fail(int code, const char* fmt, ...) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-constexpr size_t kLdsBudget = 80 * 1024;  // two workgroups per CU (160 KiB)
+constexpr size_t kLdsBudget = 80 * 1024 - 320;  // two workgroups per CU (160 KiB); 320 B spare for wgrad's zero slot
 constexpr int kMaxGrid = 512;             // 2 persistent workgroups x 256 CUs
 
 struct Plan {
@@ -255,10 +255,12 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     a.pad_t = pt; a.pad_l = pl; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
     a.stagger = stagger_sleeps(p);
+    a.zero_slot = (p.TH + d->KH - 1) * p.RS + (d->KW - 1);      // first slot after the largest tile
+    const size_t wg_lds = p.lds_bytes + (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
-    if (!launch_wgrad(k, a, p.grid, p.lds_bytes, s, &err))
+    if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
                     p.nch);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
