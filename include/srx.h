@@ -150,6 +150,13 @@ int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel,
 int srx_momentum_clip_step(float* w, const float* g, float* acc, size_t numel, float lr,
                            float momentum, float cap, float grad_scale, srx_stream_t stream);
 
+/* SRCNN's loss (srcnn/srcnn.py:142-144): rows = reshape(pred - target, [-1, row_len]);
+ *   *loss_out = mean_rows( ||row||_2 )        dpred = d / (||row||_2 * rows)   (dpred nullable)
+ * (the reference reshapes to [-1, bb*bb], so a row mixes channels: 3 rows per RGB image).
+ * row_norms: caller-owned device scratch of `rows` floats. */
+int srx_rownorm_loss_fwd_bwd(const float* pred, const float* target, size_t rows, size_t row_len,
+                             float* loss_out, float* dpred, float* row_norms, srx_stream_t stream);
+
 /* tf.image.psnr(a,b,max_val) per image: out[n] = 20log10(max) - 10log10(mean((a-b)^2)).
  * vdsr/vdsr/experiment_train.py:80-82, vdsr/vdsr/experiment_evaluate.py:57-60. */
 int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val,

@@ -13,6 +13,8 @@ hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, f
                        float gs, hipStream_t s);
 hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float lr, float mom, float cap, float gs,
                            hipStream_t s);
+hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t rows, size_t row_len, float* loss,
+                               float* dpred, float* norms, hipStream_t s);
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s);
 hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b, hipStream_t s);
 hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s);

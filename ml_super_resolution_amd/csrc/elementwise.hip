@@ -339,6 +339,42 @@ __global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __re
     }
 }
 
+// SRCNN loss: one block per row computes ||pred-target||_2 of that row; a second pass scales.
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      size_t row_len, float* __restrict__ norms) {
+    __shared__ float sh[4];
+    const float* pa = a + (size_t)blockIdx.x * row_len;
+    const float* pb = b + (size_t)blockIdx.x * row_len;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < row_len; i += 256) {
+        const float d = pa[i] - pb[i];
+        acc += d * d;
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(t);
+}
+
+__global__ __launch_bounds__(256) void rownorm_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           size_t rows, size_t row_len, const float* __restrict__ norms,
+                                                           float* __restrict__ dpred) {
+    const size_t n = rows * row_len;
+    const float inv_rows = 1.0f / (float)rows;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float nr = norms[i / row_len];
+        dpred[i] = nr > 0.f ? (a[i] - b[i]) * inv_rows / nr : 0.f;
+    }
+}
+
+hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t rows, size_t row_len, float* loss,
+                               float* dpred, float* norms, hipStream_t s) {
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)rows), dim3(256), 0, s, pred, target, row_len, norms);
+    if (loss) hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, norms, (int)rows, 1.0f / (float)rows, loss, 0);
+    if (dpred)
+        hipLaunchKernelGGL(rownorm_grad_kernel, dim3(ew_grid(rows * row_len, 1)), dim3(256), 0, s, pred, target, rows,
+                           row_len, norms, dpred);
+    return hipGetLastError();
+}
+
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s) {
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, y, dpre, n, act);
     return hipGetLastError();

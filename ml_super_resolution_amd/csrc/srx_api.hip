@@ -336,6 +336,14 @@ int srx_momentum_clip_step(float* w, const float* g, float* acc, size_t numel, f
     SRX_CHECK_LAUNCH(launch_momentum(w, g, acc, numel, lr, momentum, cap, grad_scale, (hipStream_t)stream), "momentum");
 }
 
+int srx_rownorm_loss_fwd_bwd(const float* pred, const float* target, size_t rows, size_t row_len, float* loss_out,
+                             float* dpred, float* row_norms, srx_stream_t stream) {
+    if (!pred || !target || !row_norms) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (rows == 0 || row_len == 0 || rows > (1u << 30)) return fail(SRX_ERR_BAD_ARG, "bad row-norm dims");
+    SRX_CHECK_LAUNCH(launch_rownorm_loss(pred, target, rows, row_len, loss_out, dpred, row_norms, (hipStream_t)stream),
+                     "rownorm loss");
+}
+
 int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val, srx_stream_t stream) {
     if (!a || !b || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
     if (N <= 0 || per_image == 0) return fail(SRX_ERR_BAD_ARG, "bad psnr dims");

@@ -77,6 +77,7 @@ class ConvStack(object):
         self._bufs = {}
         self._ws = None
         self.grad_hook = None      # called with the flat gradient after backward (DP all-reduce)
+        self.loss_kind = 'mse'     # 'mse' (VDSR, ESPCN) or 'rownorm' (SRCNN)
 
     # ---- parameter views -------------------------------------------------------------------
     def kernel(self, i, buf=None):
@@ -162,8 +163,12 @@ class ConvStack(object):
         y = acts[-1]
         last = len(self.specs) - 1
         inv = 1.0 / (y.numel() if numel_global is None else numel_global)
-        dy = self._buf(('dy', 0), y.shape)
-        ops.mse_fwd_bwd(y, target, self.loss, inv_numel=inv, accumulate=False, dpred=dy)
+        if self.loss_kind == 'rownorm':
+            # srcnn/srcnn.py:142-144: mean over rows of ||reshape(diff, [-1, bb*bb])||_2
+            dy = ops.rownorm_loss_fwd_bwd(y, target, y.shape[1] * y.shape[2], self.loss)
+        else:
+            dy = self._buf(('dy', 0), y.shape)
+            ops.mse_fwd_bwd(y, target, self.loss, inv_numel=inv, accumulate=False, dpred=dy)
         if self.weight_decay:
             for i in range(len(self.specs)):
                 ops.l2_loss(self.kernel(i), self.weight_decay, self.loss, accumulate=True)

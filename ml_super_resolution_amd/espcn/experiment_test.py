@@ -1,0 +1,115 @@
+"""
+experiment_test.py -- mirror of espcn/espcn/experiment_test.py: super-resolve one image, or
+evaluate PSNR over a directory.  The conv stack and the depth-to-space map (the reference's host
+NumPy split/reshape/concatenate, :171-177) run on the GPU; image file I/O stays on the host.
+
+  python -m ml_super_resolution_amd.espcn.experiment_test --ckpt_path model.npz \
+         --data_path lr.png --result_path sr.png
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from .. import graph, ops
+from . import model_espcn
+
+
+def build_model(FLAGS):
+    """experiment_test.py:14-57 (meta_path is accepted for flag compatibility and ignored)."""
+    model = model_espcn.build_test_model(getattr(FLAGS, 'meta_path', None), FLAGS.ckpt_path)
+    model['hr_targets'] = graph.placeholder([None, None, None, 3 * model['scaling_factor'] ** 2])
+    return model
+
+
+def space_to_depth_numpy(hr_image, upscaling_factor):
+    """Host label layout of experiment_test.py:91-96 (kept for callers that prepare labels on CPU)."""
+    h, w, _ = hr_image.shape
+    patches = np.split(hr_image, w // upscaling_factor, axis=1)
+    patches = [np.reshape(im, [h // upscaling_factor, 1, -1]) for im in patches]
+    return np.concatenate(patches, axis=1)
+
+
+def prepare_image_pair(hr_image, upscaling_factor):
+    """experiment_test.py:60-98 on an already decoded uint8 image: trim, map to [-1,1], gaussian
+    blur sigma = 0.5*(r-1) with 'nearest' borders, decimate at offset r//2, and the sub-pixel label.
+    (skimage is not available here; scipy.ndimage.gaussian_filter is the routine it wraps --
+    parity with skimage unpinned.)"""
+    from scipy.ndimage import gaussian_filter
+    h, w, _ = hr_image.shape
+    h -= h % upscaling_factor
+    w -= w % upscaling_factor
+    hr = hr_image[:h, :w] / 127.5 - 1.0
+    sigma = max(0.0, 0.5 * (upscaling_factor - 1.0))
+    bl = gaussian_filter(hr, sigma=(sigma, sigma, 0), mode='nearest', truncate=4.0) if sigma > 0 else hr
+    offset = upscaling_factor // 2
+    lr = bl[offset::upscaling_factor, offset::upscaling_factor]
+    return lr.astype(np.float32), space_to_depth_numpy(hr, upscaling_factor).astype(np.float32)
+
+
+def psnr_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
+    """experiment_test.py:32-54: map to [0,1], clip, optionally keep only Y of rgb_to_yuv
+    (0.299, 0.587, 0.114), PSNR with max_val 1.  PSNR is permutation invariant, so it is evaluated
+    directly in sub-pixel space as the reference does."""
+    sr = ops.affine(sr_results, 0.5, 0.5).clamp_(0.0, 1.0)
+    hr = ops.affine(hr_targets, 0.5, 0.5).clamp_(0.0, 1.0)
+    if score_space == 'y':
+        n, h, w, d = sr.shape
+        wts = torch.tensor([0.299, 0.587, 0.114], device=sr.device)
+        sr = (sr.reshape(n, h, w * (d // 3), 3) * wts).sum(-1, keepdim=True).contiguous()
+        hr = (hr.reshape(n, h, w * (d // 3), 3) * wts).sum(-1, keepdim=True).contiguous()
+    return ops.psnr(hr, sr, 1.0)
+
+
+def super_resolve_array(model, lr_image):
+    """experiment_test.py:159-181 on a decoded image: [h,w,3] uint8 -> [h*r,w*r,3] float in [0,1]."""
+    m = model['_model']
+    lr = torch.from_numpy(np.ascontiguousarray(lr_image, dtype=np.float32)).to(m.stack.device)
+    lr = ops.affine(lr.unsqueeze(0).contiguous(), 1.0 / 127.5, -1.0)
+    sr = m.super_resolve(lr)                                   # conv stack + depth-to-space on the GPU
+    sr = ops.affine(sr, 0.5, 0.5).clamp_(0.0, 1.0)
+    return sr[0].cpu().numpy()
+
+
+def super_resolve_image(FLAGS):
+    from PIL import Image
+    model = build_model(FLAGS)
+    lr_image = np.asarray(Image.open(FLAGS.data_path).convert('RGB'))
+    sr = super_resolve_array(model, lr_image)
+    Image.fromarray((sr * 255.0 + 0.5).astype(np.uint8)).save(FLAGS.result_path)
+
+
+def evaluate_images(FLAGS):
+    from PIL import Image
+    model = build_model(FLAGS)
+    m = model['_model']
+    names = [n for n in sorted(os.listdir(FLAGS.data_path)) if n[-4:] in ['.png', '.jpg', '.bmp']]
+    psnrs = []
+    for name in names:
+        hr_image = np.asarray(Image.open(os.path.join(FLAGS.data_path, name)).convert('RGB'))
+        lr, hr = prepare_image_pair(hr_image, model['scaling_factor'])
+        sr = m.forward(torch.from_numpy(lr[None]).to(m.stack.device))
+        p = psnr_in_subpixel_space(model, sr, torch.from_numpy(hr[None]).to(m.stack.device), FLAGS.score_space)
+        psnrs.append(float(p[0]))
+        print('name: {:>32}, psnr: {:.4f}'.format(name, psnrs[-1]))
+    print('data: {}'.format(FLAGS.data_path))
+    print('psnr: {0:.4f}'.format(float(np.mean(psnrs))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--meta_path', default=None)
+    ap.add_argument('--ckpt_path', required=True)
+    ap.add_argument('--data_path', required=True)
+    ap.add_argument('--result_path', default=None)
+    ap.add_argument('--score_space', default='y')
+    FLAGS = ap.parse_args()
+    if os.path.isdir(FLAGS.data_path):
+        evaluate_images(FLAGS)
+    else:
+        super_resolve_image(FLAGS)
+
+
+if __name__ == '__main__':
+    main()

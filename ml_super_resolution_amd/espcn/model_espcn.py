@@ -1,0 +1,144 @@
+"""
+model_espcn.py -- mirror of espcn/espcn/model_espcn.py (reference) on the MI355X engine.
+
+  build_model(lr_source, scaling_factor=3, hr_target=None)
+      -> {'lr_source', 'sr_result'} (+ 'hr_target', 'step', 'loss', 'optimizer', 'learning_rate')
+  build_test_model(meta_path, ckpt_path) -> {'lr_sources', 'sr_results', 'scaling_factor'}
+  extract_weights(meta_path, ckpt_path)  -> {'f1/kernel:0': ndarray, ...}
+(reference: model_espcn.py:6,17-19,64,71,91-94,143-147,150-166).
+
+Network (model_espcn.py:30-62 / :117-134): 5x5 conv -> 64 tanh, 3x3 -> 32 tanh, 3x3 -> 3*r*r linear,
+all SAME.  `sr_result` stays in sub-pixel space [N,H,W,3*r*r], exactly like the reference; the
+depth-to-space map is a separate op (ops.depth_to_space == experiment_test.py:171-177).
+Checkpoints: the reference restores a TF bundle + .meta graph; here a checkpoint is an .npz of the
+same variable names (`f1/kernel:0` ...), `meta_path` is accepted and ignored.
+"""
+import numpy as np
+import torch
+
+from .. import graph, ops
+from ..engine import ConvStack, LayerSpec, truncated_normal_
+
+
+def layer_specs(scaling_factor=3):
+    r2 = scaling_factor * scaling_factor
+    return [LayerSpec(5, 3, 64, 'same', 'tanh', 'f1'),
+            LayerSpec(3, 64, 32, 'same', 'tanh', 'f2'),
+            LayerSpec(3, 32, 3 * r2, 'same', None, 'f3')]
+
+
+class EspcnModel(object):
+    def __init__(self, scaling_factor=3, device='cuda', seed=None):
+        self.scaling_factor = scaling_factor
+        self.stack = ConvStack(layer_specs(scaling_factor), device=device, residual=False, weight_decay=0.0)
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        for i in range(3):
+            truncated_normal_(self.stack.kernel(i), 0.02, gen)      # model_espcn.py:21; biases zero
+        self.placeholders = {}
+
+    # ---- eager API -----------------------------------------------------------------------------
+    def forward(self, lr_source, keep=False):
+        """sr_result in sub-pixel space [N,H,W,3*r*r]."""
+        return self.stack.forward(lr_source, keep=keep)
+
+    def super_resolve(self, lr_source):
+        """forward + depth-to-space: [N,H,W,3] -> [N,H*r,W*r,3]."""
+        return ops.depth_to_space(self.forward(lr_source), self.scaling_factor)
+
+    def train_step(self, lr_source, hr_target, learning_rate):
+        """MSE in sub-pixel space (hr_target is the space-to-depth label, dataset.py:140-156) + Adam
+        with the fed learning rate (model_espcn.py:76-89)."""
+        self.stack.forward(lr_source, keep=True)
+        loss = self.stack.loss_and_backward(hr_target)
+        self.stack.adam_step(learning_rate)
+        return loss
+
+    # ---- checkpoints ---------------------------------------------------------------------------
+    def save(self, path):
+        arrays = {k + ':0': v.detach().cpu().numpy() for k, v in self.stack.variables().items()}
+        arrays['global_step'] = np.int64(self.stack.global_step)
+        np.savez(path, **arrays)
+
+    # ---- Session.run backend -------------------------------------------------------------------
+    def run(self, keys, feed_dict):
+        dev = self.stack.device
+        feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}
+        if 'lr_source' not in feeds:
+            raise ValueError('lr_source must be fed')
+        lr = graph.to_device(feeds['lr_source'], dev)
+        hr = graph.to_device(feeds['hr_target'], dev) if 'hr_target' in feeds else None
+        loss = None
+        if 'optimizer' in keys:
+            if hr is None or 'learning_rate' not in feeds:
+                raise ValueError('hr_target and learning_rate must be fed to run the optimizer')
+            loss = self.train_step(lr, hr, float(feeds['learning_rate']))
+            y = self.stack.acts[-1]
+        else:
+            y = self.stack.forward(lr, keep=True)
+            if 'loss' in keys:
+                if hr is None:
+                    raise ValueError('hr_target must be fed to fetch loss')
+                loss = self.stack.loss
+                ops.mse_fwd_bwd(y, hr, loss, accumulate=False, want_grad=False)
+        out = {}
+        for k in keys:
+            if k == 'optimizer':
+                out[k] = None
+            elif k == 'loss':
+                out[k] = float(loss.item())
+            elif k == 'step':
+                out[k] = self.stack.global_step
+            elif k in ('sr_result', 'sr_results'):
+                out[k] = y.detach().cpu().numpy()
+            elif k in ('lr_source', 'lr_sources'):
+                out[k] = lr.detach().cpu().numpy()
+            elif k == 'hr_target':
+                out[k] = hr.detach().cpu().numpy()
+            else:
+                raise KeyError(k)
+        return out
+
+
+def build_model(lr_source, scaling_factor=3, hr_target=None, device='cuda', seed=None):
+    """
+    lr_source:  source image batch (graph.placeholder) to be super resolved
+    hr_target:  target batch as training labels in sub-pixel convolved shape; a partial (test)
+                model is built if hr_target is None
+    scaling_factor: factor of up scaling; the depth of the final layer is 3 * scaling_factor ** 2
+    """
+    m = EspcnModel(scaling_factor, device=device, seed=seed)
+    m.placeholders['lr_source'] = lr_source
+    model = {'lr_source': lr_source, '_model': m}
+    model['sr_result'] = graph.Tensor('sr_result', owner=m, key='sr_result')
+    if hr_target is None:
+        return model
+    m.placeholders['hr_target'] = hr_target
+    lr = graph.placeholder([], name='learning_rate')         # tf.placeholder(shape=[]) (model_espcn.py:83)
+    m.placeholders['learning_rate'] = lr
+    model['hr_target'] = hr_target
+    model['step'] = graph.Tensor('global_step', owner=m, key='step')
+    model['loss'] = graph.Tensor('loss', owner=m, key='loss')
+    model['optimizer'] = graph.Tensor('optimizer', owner=m, key='optimizer')
+    model['learning_rate'] = lr
+    return model
+
+
+def extract_weights(meta_path, ckpt_path):
+    """{variable name: ndarray} for every trainable variable (model_espcn.py:150-166)."""
+    z = np.load(ckpt_path)
+    return {k: z[k] for k in z.files if k.endswith(':0')}
+
+
+def build_test_model(meta_path, ckpt_path, device='cuda'):
+    """Weights-as-constants inference model with dynamic image size (model_espcn.py:99-147).
+    `ckpt_path` may also be an already-loaded {name: array} dict."""
+    variables = ckpt_path if isinstance(ckpt_path, dict) else extract_weights(meta_path, ckpt_path)
+    scaling_factor = int((np.asarray(variables['f3/bias:0']).size // 3) ** 0.5)      # model_espcn.py:108
+    m = EspcnModel(scaling_factor, device=device)
+    m.stack.load_variables(variables)
+    lr_sources = graph.placeholder([None, None, None, 3], name='lr_sources')
+    m.placeholders['lr_source'] = lr_sources
+    return {'lr_sources': lr_sources,
+            'sr_results': graph.Tensor('sr_results', owner=m, key='sr_results'),
+            'scaling_factor': scaling_factor,
+            '_model': m}

@@ -159,6 +159,19 @@ def momentum_clip_step(w, g, acc, lr, momentum=0.9, cap=float('inf'), grad_scale
                                        float(grad_scale), _stream()), 'srx_momentum_clip_step')
 
 
+def rownorm_loss_fwd_bwd(pred, target, row_len, loss_out, want_grad=True):
+    """SRCNN loss: mean over rows of ||reshape(pred-target, [-1,row_len])||_2 (+ its gradient)."""
+    _chk(pred, 'pred'); _chk(target, 'target')
+    rows = pred.numel() // row_len
+    if rows * row_len != pred.numel():
+        raise ValueError('numel %d not divisible by row_len %d' % (pred.numel(), row_len))
+    norms = torch.empty(rows, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    check(lib().srx_rownorm_loss_fwd_bwd(_ptr(pred), _ptr(target), rows, row_len, _ptr(loss_out), _ptr(dpred),
+                                         _ptr(norms), _stream()), 'srx_rownorm_loss_fwd_bwd')
+    return dpred
+
+
 def psnr(a, b, max_val):
     _chk(a, 'a'); _chk(b, 'b')
     N = a.shape[0]

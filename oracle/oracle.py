@@ -348,6 +348,15 @@ def srcnn_loss(sr, hi):
     return float(np.sqrt((d * d).sum(axis=1)).mean())
 
 
+def srcnn_loss_and_grad(sr, hi):
+    """Loss of srcnn.py:142-144 and d loss / d sr."""
+    sr = np.asarray(sr, np.float64)
+    bb = sr.shape[1]
+    d = (sr - np.asarray(hi, np.float64)).reshape(-1, bb * bb)
+    nr = np.sqrt((d * d).sum(axis=1, keepdims=True))
+    return float(nr.mean()), (d / nr / d.shape[0]).reshape(sr.shape)
+
+
 # ----------------------------------------------------------------------------
 # C restatement (srx_oracle.c) via ctypes -- used for larger cases and as the
 # cpu_baseline "port"

@@ -1,0 +1,133 @@
+"""ESPCN and SRCNN through the reference-shaped entry points, against golden vectors / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.golden.make_golden import espcn_params, srcnn_params
+from tests.test_gpu_ops import close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('r', [3, 4])
+def test_espcn_test_model_and_d2s(r, golden_nets, tmp_path):
+    from ml_super_resolution_amd import graph, ops
+    from ml_super_resolution_amd.espcn import model_espcn, experiment_test
+    g = golden_nets
+    params = espcn_params(103 + r, r)
+    # checkpoint with the reference's variable names; build_test_model infers the scale from f3/bias
+    ck = {}
+    for name, (k, b) in zip(('f1', 'f2', 'f3'), params):
+        ck[name + '/kernel:0'] = k
+        ck[name + '/bias:0'] = b
+    path = str(tmp_path / 'model.ckpt.npz')
+    np.savez(path, **ck)
+    assert set(model_espcn.extract_weights(None, path)) == set(ck)
+    model = model_espcn.build_test_model(None, path)
+    assert model['scaling_factor'] == r
+    assert set(k for k in model if not k.startswith('_')) == {'lr_sources', 'sr_results', 'scaling_factor'}
+    with graph.Session() as session:
+        sr = session.run(model['sr_results'], feed_dict={model['lr_sources']: g['espcn%d.lr' % r]})
+    close(sr, g['espcn%d.y' % r])
+    # depth-to-space of the GPU result is the same permutation as the oracle's
+    hr = ops.depth_to_space(dev(sr), r).cpu().numpy()
+    np.testing.assert_array_equal(hr, O.depth_to_space(sr, r))
+    close(hr, g['espcn%d.d2s' % r])
+    # reference host spelling (experiment_test.py:171-177) on image 0
+    np.testing.assert_array_equal(hr[0], O.d2s_ref_spelling_test(sr[0], r))
+    # label layout helper == space_to_depth op == reference spelling (dataset.py:140-156)
+    lab = experiment_test.space_to_depth_numpy(hr[0], r)
+    np.testing.assert_array_equal(lab, sr[0])
+    np.testing.assert_array_equal(ops.space_to_depth(dev(hr), r).cpu().numpy(), sr)
+
+
+def test_espcn_train_step_vs_oracle():
+    from ml_super_resolution_amd import graph
+    from ml_super_resolution_amd.espcn import model_espcn
+    r = 3
+    lr_ph = graph.placeholder([None, None, None, 3])
+    hr_ph = graph.placeholder([None, None, None, 3 * r * r])
+    model = model_espcn.build_model(lr_ph, r, hr_ph)
+    assert set(k for k in model if not k.startswith('_')) == {'lr_source', 'sr_result', 'hr_target', 'step', 'loss',
+                                                               'optimizer', 'learning_rate'}
+    params = espcn_params(200, r)
+    m = model['_model']
+    m.stack.set_params(params)
+    rng = np.random.default_rng(21)
+    lr = rng.uniform(-1, 1, (4, 17, 17, 3)).astype(np.float32)
+    hr = rng.uniform(-1, 1, (4, 51, 51, 3)).astype(np.float32)
+    target = O.space_to_depth(hr, r)
+    with graph.Session() as session:
+        out = session.run({'step': model['step'], 'loss': model['loss'], 'optimizer': model['optimizer']},
+                          feed_dict={model['lr_source']: lr, model['hr_target']: target, model['learning_rate']: 0.01})
+    # oracle: forward, MSE in sub-pixel space, backward through tanh/tanh/linear, TF-Adam
+    (k1, b1), (k2, b2), (k3, b3) = [(k.astype(np.float64), b.astype(np.float64)) for k, b in params]
+    t1 = O.conv2d_fwd(lr, k1, b1, 'SAME', 'tanh'); t2 = O.conv2d_fwd(t1, k2, b2, 'SAME', 'tanh')
+    y = O.conv2d_fwd(t2, k3, b3, 'SAME', None)
+    loss, dy = O.mse_fwd_bwd(y, target)
+    assert out['step'] == 1 and abs(out['loss'] - loss) <= 1e-4 * loss
+    dk3, db3 = O.conv2d_bwd_filter(t2, dy, (3, 3)); d2 = O.conv2d_bwd_data(dy, k3, (17, 17)) * (1 - t2 * t2)
+    dk2, db2 = O.conv2d_bwd_filter(t1, d2, (3, 3)); d1 = O.conv2d_bwd_data(d2, k2, (17, 17)) * (1 - t1 * t1)
+    dk1, db1 = O.conv2d_bwd_filter(lr, d1, (5, 5))
+    st = m.stack
+    for i, (dk, db) in enumerate(((dk1, db1), (dk2, db2), (dk3, db3))):
+        close(st.kernel(i, st.grads), dk)
+        close(st.bias(i, st.grads), db)
+    close(st.kernel(0), O.adam_tf(k1, dk1, 0.0, 0.0, 0.01, 1)[0], 1e-4)
+
+
+def test_srcnn_forward_and_train_vs_oracle(golden_nets):
+    from ml_super_resolution_amd import graph
+    from ml_super_resolution_amd.srcnn import srcnn
+    g = golden_nets
+    flags = srcnn._flags().parse_args(['--train', '--crop-image-size', '33'])
+    srcnn.sanity_check(flags)
+    assert (flags.crop_image_side, flags.crop_image_size) == (6, 33)
+    model = srcnn.build_srcnn(flags=flags)
+    assert set(k for k in model if not k.startswith('_')) == {'step', 'loss', 'trainer', 'hd_images', 'sd_images', 'sr_images'}
+    m = model['_model']
+    params = srcnn_params(107)
+    m.stack.set_params(params)
+    hd_full = np.random.default_rng(5).uniform(-1, 1, (1, 33, 33, 3)).astype(np.float32)
+    feed = {model['_feed_sd_images']: g['srcnn.lo'], model['_feed_hd_images']: hd_full}
+    with graph.Session() as session:
+        out = session.run({'sr': model['sr_images'], 'loss': model['loss'], 'hd': model['hd_images']}, feed_dict=feed)
+    assert out['sr'].shape == (1, 21, 21, 3) and out['hd'].shape == (1, 21, 21, 3)
+    close(out['sr'], g['srcnn.y'])
+    np.testing.assert_array_equal(out['hd'], hd_full[:, 6:27, 6:27])
+    ref_loss, dsr = O.srcnn_loss_and_grad(O.srcnn_forward(g['srcnn.lo'], params), hd_full[:, 6:27, 6:27])
+    assert abs(out['loss'] - ref_loss) <= 1e-4 * ref_loss
+    # one Adam(1e-3, .5, .9) step; check the gradient of the last layer against the oracle
+    with graph.Session() as session:
+        o2 = session.run({'step': model['step'], 'trainer': model['trainer'], 'loss': model['loss']}, feed_dict=feed)
+    assert o2['step'] == 1
+    (k1, b1), (k2, b2), (k3, b3) = params
+    t1 = O.conv2d_fwd(g['srcnn.lo'], k1, b1, 'VALID', 'relu'); t2 = O.conv2d_fwd(t1, k2, b2, 'VALID', 'relu')
+    y = O.conv2d_fwd(t2, k3, b3, 'VALID', 'tanh')
+    dpre3 = dsr * (1 - y * y)
+    dk3, db3 = O.conv2d_bwd_filter(t2, dpre3, (5, 5), 'VALID')
+    close(m.stack.kernel(2, m.stack.grads), dk3)
+    close(m.stack.bias(2, m.stack.grads), db3)
+    d2 = O.conv2d_bwd_data(dpre3, k3, t2.shape[1:3], 'VALID') * (t2 > 0)
+    dk2, _ = O.conv2d_bwd_filter(t1, d2, (1, 1), 'VALID')
+    close(m.stack.kernel(1, m.stack.grads), dk2)
+    d1 = O.conv2d_bwd_data(d2, k2, t1.shape[1:3], 'VALID') * (t1 > 0)
+    dk1, _ = O.conv2d_bwd_filter(g['srcnn.lo'], d1, (9, 9), 'VALID')
+    close(m.stack.kernel(0, m.stack.grads), dk1)
+
+
+def test_srcnn_config1_shape():
+    """BASELINE configs[0]: SRCNN 9-1-5 on one 256x256 image -> crop 243 -> 231x231 (pin P4)."""
+    from ml_super_resolution_amd.srcnn import srcnn
+    flags = srcnn._flags().parse_args([])
+    srcnn.sanity_check(flags)
+    assert (flags.crop_image_side, flags.crop_image_size, flags.batch_size) == (6, 243, 1)
+    m = srcnn.SrcnnModel(flags, seed=3)
+    x = torch.rand((1, 243, 243, 3), device='cuda') * 2 - 1
+    y = m.forward(x)
+    assert tuple(y.shape) == (1, 231, 231, 3)
+    params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
+    ref = O.c_conv2d_fwd(O.c_conv2d_fwd(O.c_conv2d_fwd(x.cpu().numpy(), *params[0], 'VALID', 'relu'), *params[1], 'VALID', 'relu'),
+                         *params[2], 'VALID', 'tanh')
+    close(y, ref)
