@@ -1,0 +1,55 @@
+"""
+dataset.py -- batch sources for the VDSR entry points.
+
+The reference's `vdsr/vdsr/dataset.py` builds (sd, hd) pairs on the host with scikit-image
+(gaussian blur sigma = 0.5*(s-1), bilinear resize down then up with mode='edge', random 41x41 crop
+and flip: dataset.py:13-38,82-128).  scikit-image is not part of this image and that CPU pipeline is
+outside the hot path, so this module offers:
+  * synthetic_batches: the benchmark's synthetic patches, generated on the GPU;
+  * npz_batches: pre-extracted patch pairs ({'sd': [M,h,w,3], 'hd': [M,h,w,3]} in [-1,1]);
+  * hd_image_to_sd_image: the same degradation restated with scipy.ndimage (parity with skimage
+    unpinned) for the evaluate / resolve entry points.
+Every generator yields device tensors: nothing is copied host->device per step.
+"""
+import numpy as np
+import torch
+
+
+def synthetic_batches(image_size, batch_size, device, seed=104):
+    g = torch.Generator(device=device).manual_seed(seed)
+    while True:
+        hd = torch.rand((batch_size, image_size, image_size, 3), device=device, generator=g) * 2 - 1
+        sd = (hd + 0.1 * torch.randn(hd.shape, device=device, generator=g)).clamp(-1, 1)
+        yield sd, hd
+
+
+def npz_batches(path, batch_size, device, seed=0):
+    z = np.load(path)
+    sd_all, hd_all = z['sd'].astype(np.float32), z['hd'].astype(np.float32)
+    rng = np.random.default_rng(seed)
+    while True:
+        idx = rng.integers(0, sd_all.shape[0], size=batch_size)
+        yield torch.from_numpy(sd_all[idx]).to(device), torch.from_numpy(hd_all[idx]).to(device)
+
+
+def hd_image_to_sd_image(hd_image, scaling_factor):
+    """dataset.py:13-38 restated with scipy: blur (nearest borders), bilinear resize down and back up
+    (edge mode, no anti-aliasing).  float image in, float image out."""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    hd_h, hd_w, _ = hd_image.shape
+    sd_h, sd_w = int(hd_h / scaling_factor), int(hd_w / scaling_factor)
+    sigma = max(0.0, 0.5 * (scaling_factor - 1.0))
+    bl = gaussian_filter(hd_image, sigma=(sigma, sigma, 0), mode='nearest', truncate=4.0) if sigma > 0 else hd_image
+
+    def resize(img, oh, ow):
+        ih, iw, c = img.shape
+        # skimage.transform.resize (order 1): output pixel centre -> input coordinate, half-pixel mapping
+        ys = (np.arange(oh) + 0.5) * ih / oh - 0.5
+        xs = (np.arange(ow) + 0.5) * iw / ow - 0.5
+        yy, xx = np.meshgrid(ys, xs, indexing='ij')
+        out = np.empty((oh, ow, c), img.dtype)
+        for ch in range(c):
+            out[:, :, ch] = map_coordinates(img[:, :, ch], [yy, xx], order=1, mode='nearest')
+        return out
+
+    return resize(resize(bl, sd_h, sd_w), hd_h, hd_w)

@@ -131,3 +131,40 @@ def test_srcnn_config1_shape():
     ref = O.c_conv2d_fwd(O.c_conv2d_fwd(O.c_conv2d_fwd(x.cpu().numpy(), *params[0], 'VALID', 'relu'), *params[1], 'VALID', 'relu'),
                          *params[2], 'VALID', 'tanh')
     close(y, ref)
+
+
+def test_enet_generator_forward_vs_oracle():
+    """EnhanceNet generator (model_enet.py:44-115): 3x3 / 1x1 convs, residual blocks with fused
+    skip + ReLU, nearest-neighbour x2 upsampling twice, + bicubic image."""
+    from ml_super_resolution_amd import graph
+    from ml_super_resolution_amd.enet import model_enet
+    sd_ph, bq_ph = graph.placeholder([None, None, None, 3]), graph.placeholder([None, None, None, 3])
+    model = model_enet.build_enet(sd_ph, bq_ph, None)
+    assert set(k for k in model if not k.startswith('_')) == {'sd_images', 'bq_images', 'sr_images'}
+    g = model['_model']
+    rng = np.random.default_rng(31)
+    pairs = []
+    for k, cin, cout in model_enet.generator_layers():
+        pairs.append((rng.normal(0, 1.0 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32),
+                      rng.uniform(-0.1, 0.1, cout).astype(np.float32)))
+    g.set_params(pairs)
+    assert len(g.variables()) == 2 * 25 and 'g_/conv2d_24/kernel' in g.variables()
+    sd = rng.uniform(-1, 1, (1, 12, 10, 3)).astype(np.float32)
+    bq = rng.uniform(-1, 1, (1, 48, 40, 3)).astype(np.float32)
+    with graph.Session() as session:
+        sr = session.run(model['sr_images'], feed_dict={sd_ph: sd, bq_ph: bq})
+    # oracle
+    t = O.c_conv2d_fwd(sd, *pairs[0], 'SAME', 'relu')
+    i = 1
+    for _ in range(10):
+        x = O.c_conv2d_fwd(t, *pairs[i], 'SAME', 'relu')
+        t = O.c_conv2d_fwd(x, *pairs[i + 1], 'SAME', None, skip=t, post_relu=True)
+        i += 2
+    for _ in range(2):
+        t = np.repeat(np.repeat(t, 2, axis=1), 2, axis=2)     # resize_nearest_neighbor by an integer factor
+        t = O.c_conv2d_fwd(t, *pairs[i], 'SAME', 'relu')
+        i += 1
+    t = O.c_conv2d_fwd(t, *pairs[i], 'SAME', 'relu')
+    ref = O.c_conv2d_fwd(t, *pairs[i + 1], 'SAME', None, skip=bq)
+    assert sr.shape == (1, 48, 40, 3)
+    close(sr, ref)
