@@ -128,10 +128,12 @@ int srx_mse_fwd_bwd(const float* pred, const float* target, size_t numel, float 
                     float* loss_out, int accumulate, float* dpred, void* scratch,
                     srx_stream_t stream);
 
-/* *loss_out (+)= scale * sum(w^2)/2  -- tf.contrib.layers.l2_regularizer(scale)(w),
- * vdsr/vdsr/model_vdsr.py:34,125. */
-int srx_l2_loss(const float* w, size_t numel, float scale, float* loss_out, int accumulate,
-                void* scratch, srx_stream_t stream);
+/* *loss_out (+)= scale * sum(mask * w^2)/2  -- sum over kernels of
+ * tf.contrib.layers.l2_regularizer(scale)(w), vdsr/vdsr/model_vdsr.py:34,125.
+ * mask (nullable) has w's shape: 1 for regularised elements (kernels), 0 otherwise (biases), so
+ * one launch covers a model's whole flat parameter buffer. */
+int srx_l2_loss(const float* w, const float* mask, size_t numel, float scale, float* loss_out,
+                int accumulate, void* scratch, srx_stream_t stream);
 
 size_t srx_reduce_scratch_bytes(void);
 

@@ -65,7 +65,7 @@ def lib():
     L.srx_depth_to_space.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srx_space_to_depth.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srx_mse_fwd_bwd.argtypes = [vp, vp, sz, f, vp, i, vp, vp, vp]
-    L.srx_l2_loss.argtypes = [vp, sz, f, vp, i, vp, vp]
+    L.srx_l2_loss.argtypes = [vp, vp, sz, f, vp, i, vp, vp]
     L.srx_adam_tf_step.argtypes = [vp, vp, vp, vp, sz, f, f, f, f, ctypes.c_int64, f, vp]
     L.srx_momentum_clip_step.argtypes = [vp, vp, vp, sz, f, f, f, f, vp]
     L.srx_rownorm_loss_fwd_bwd.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]

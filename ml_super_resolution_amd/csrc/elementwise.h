@@ -8,7 +8,8 @@ constexpr int kReduceBlocks = 1024;  // partial slots a reduction may use (srx_r
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse, hipStream_t s);
 hipError_t launch_mse(const float* pred, const float* target, size_t n, float inv, float* loss, int accumulate,
                       float* dpred, float* scratch, hipStream_t s);
-hipError_t launch_l2(const float* w, size_t n, float scale, float* loss, int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_l2(const float* w, const float* mask, size_t n, float scale, float* loss, int accumulate, float* scratch,
+                     hipStream_t s);
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                        float gs, hipStream_t s);
 hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float lr, float mom, float cap, float gs,

@@ -150,7 +150,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return t;  // valid in wave 0
 }
 
-// MODE 0: (a-b)^2, also writes dpred = 2*(a-b)*inv ; MODE 1: a^2
+// MODE 0: (a-b)^2, also writes dpred = 2*(a-b)*inv ; MODE 1: a^2 (times b as a 0/1 mask when b != null)
 template <int MODE>
 __global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          size_t n, float inv, float* __restrict__ dpred,
@@ -164,8 +164,13 @@ __global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict
             const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
             va -= vb;
             if (dpred) reinterpret_cast<f32x4*>(dpred)[i] = va * (2.0f * inv);
+            acc += va[0] * va[0] + va[1] * va[1] + va[2] * va[2] + va[3] * va[3];
+        } else if (b) {
+            const f32x4 m = reinterpret_cast<const f32x4*>(b)[i];
+            acc += m[0] * va[0] * va[0] + m[1] * va[1] * va[1] + m[2] * va[2] * va[2] + m[3] * va[3] * va[3];
+        } else {
+            acc += va[0] * va[0] + va[1] * va[1] + va[2] * va[2] + va[3] * va[3];
         }
-        acc += va[0] * va[0] + va[1] * va[1] + va[2] * va[2] + va[3] * va[3];
     }
     if (blockIdx.x == 0) {
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict
                 d -= b[i];
                 if (dpred) dpred[i] = d * (2.0f * inv);
             }
-            acc += d * d;
+            acc += (MODE == 1 && b) ? b[i] * d * d : d * d;
         }
     }
     const float t = block_sum(acc, sh);
@@ -212,10 +217,10 @@ hipError_t launch_mse(const float* pred, const float* target, size_t n, float in
     return hipGetLastError();
 }
 
-hipError_t launch_l2(const float* w, size_t n, float scale, float* loss, int accumulate, float* scratch,
-                     hipStream_t s) {
+hipError_t launch_l2(const float* w, const float* mask, size_t n, float scale, float* loss, int accumulate,
+                     float* scratch, hipStream_t s) {
     const int grid = reduce_grid(n);
-    hipLaunchKernelGGL(sq_partial_kernel<1>, dim3(grid), dim3(256), 0, s, w, (const float*)nullptr, n, 0.f,
+    hipLaunchKernelGGL(sq_partial_kernel<1>, dim3(grid), dim3(256), 0, s, w, mask, n, 0.f,
                        (float*)nullptr, scratch);
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, scratch, grid, 0.5f * scale, loss, accumulate);
     return hipGetLastError();

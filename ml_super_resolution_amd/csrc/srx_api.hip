@@ -309,12 +309,13 @@ int srx_mse_fwd_bwd(const float* pred, const float* target, size_t numel, float 
                                 (hipStream_t)stream), "mse");
 }
 
-int srx_l2_loss(const float* w, size_t numel, float scale, float* loss_out, int accumulate, void* scratch,
-                srx_stream_t stream) {
+int srx_l2_loss(const float* w, const float* mask, size_t numel, float scale, float* loss_out, int accumulate,
+                void* scratch, srx_stream_t stream) {
     if (!w || !loss_out || !scratch) return fail(SRX_ERR_BAD_ARG, "null pointer");
-    if (!aligned16(w)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (!aligned16(w) || (mask && !aligned16(mask)))
+        return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     if (numel == 0) return SRX_OK;
-    SRX_CHECK_LAUNCH(launch_l2(w, numel, scale, loss_out, accumulate, (float*)scratch, (hipStream_t)stream), "l2");
+    SRX_CHECK_LAUNCH(launch_l2(w, mask, numel, scale, loss_out, accumulate, (float*)scratch, (hipStream_t)stream), "l2");
 }
 
 int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel, float lr, float beta1, float beta2,

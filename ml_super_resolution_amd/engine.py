@@ -78,6 +78,7 @@ class ConvStack(object):
         self._ws = None
         self.grad_hook = None      # called with the flat gradient after backward (DP all-reduce)
         self.loss_kind = 'mse'     # 'mse' (VDSR, ESPCN) or 'rownorm' (SRCNN)
+        self._decay_mask = None
 
     # ---- parameter views -------------------------------------------------------------------
     def kernel(self, i, buf=None):
@@ -170,8 +171,7 @@ class ConvStack(object):
             dy = self._buf(('dy', 0), y.shape)
             ops.mse_fwd_bwd(y, target, self.loss, inv_numel=inv, accumulate=False, dpred=dy)
         if self.weight_decay:
-            for i in range(len(self.specs)):
-                ops.l2_loss(self.kernel(i), self.weight_decay, self.loss, accumulate=True)
+            self.add_regulariser_loss()
         if self.specs[last].act is not None:
             dpre = ops.act_bwd(dy, y, self.specs[last].act, out=self._buf(('dpre_last',), y.shape))
         else:
@@ -194,6 +194,14 @@ class ConvStack(object):
         if self.grad_hook is not None:
             self.grad_hook(self.grads)
         return self.loss
+
+    def add_regulariser_loss(self):
+        """self.loss += weight_decay * sum over kernels of sum(w^2)/2 -- one launch over the flat buffer."""
+        if self._decay_mask is None:
+            self._decay_mask = torch.zeros_like(self.params)
+            for k_off, kn, _, _ in self.slices:
+                self._decay_mask[k_off:k_off + kn] = 1.0
+        ops.l2_loss(self.params, self.weight_decay, self.loss, accumulate=True, mask=self._decay_mask)
 
     # ---- optimizers ---------------------------------------------------------------------------
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -138,9 +138,10 @@ def mse_fwd_bwd(pred, target, loss_out, inv_numel=None, accumulate=False, dpred=
     return dpred
 
 
-def l2_loss(w, scale, loss_out, accumulate=True):
-    _chk(w, 'w')
-    check(lib().srx_l2_loss(_ptr(w), w.numel(), float(scale), _ptr(loss_out), int(accumulate),
+def l2_loss(w, scale, loss_out, accumulate=True, mask=None):
+    """loss_out (+)= scale * sum(mask * w^2) / 2; mask selects the regularised elements of a flat buffer."""
+    _chk(w, 'w'); _chk(mask, 'mask')
+    check(lib().srx_l2_loss(_ptr(w), _ptr(mask), w.numel(), float(scale), _ptr(loss_out), int(accumulate),
                             _ptr(reduce_scratch(w.device)), _stream()), 'srx_l2_loss')
 
 

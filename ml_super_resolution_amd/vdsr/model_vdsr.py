@@ -92,8 +92,7 @@ class VdsrModel(object):
             if want_loss:
                 loss = self.stack.loss
                 ops.mse_fwd_bwd(sr, hd, loss, accumulate=False, want_grad=False)
-                for i in range(self.num_layers):
-                    ops.l2_loss(self.stack.kernel(i), self.stack.weight_decay, loss, accumulate=True)
+                self.stack.add_regulariser_loss()
         out = {}
         taps = None
         for k in keys:
