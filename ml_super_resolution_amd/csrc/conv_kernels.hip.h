@@ -199,10 +199,18 @@ __device__ __forceinline__ float act_slope(int act) {
     return act == ACT_RELU ? 0.0f : (act == ACT_LRELU ? 0.2f : 1.0f);
 }
 
+// tanh / sigmoid live OUT OF LINE: inlined, their code (x4 elements x every accumulator x every
+// group body) pushed the 3x3x64 kernel to 60 KB, the size of the instruction cache two CUs share,
+// and the VALU-dense staging / epilogue code then ran at instruction-fetch speed.
+__device__ __attribute__((noinline)) f32x4 act_transcendental4(f32x4 v, int act) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
+    return v;
+}
+
 __device__ __forceinline__ f32x4 act_apply4(f32x4 v, int act, float slope) {
     if (act == ACT_TANH || act == ACT_SIGMOID) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
+        v = act_transcendental4(v, act);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
@@ -316,9 +324,11 @@ __device__ __forceinline__ void mfma_block(f32x4 (&c)[4], float w0, float w1, fl
 template <int KH, int KW, int CINP, int G, bool GUARD, bool AUX>
 __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[KH * KW * (CINP / 4)],
                                            const f32x4 bias4, const ConvArgs& a, int n, int h, int ow0,
-                                           int th, int tw, float inv_tw, int m_first, int m_step,
+                                           int th, int tw, float inv_tw, int m_first, int m_step, int n_active,
                                            int li, int kq, int cout0, unsigned long long& t_mfma, unsigned long long& t_pro,
                                            unsigned long long& t_epi) {
+    // n_active <= G: sub-tiles beyond it are dummies (computed on pixel 0, never stored), so that only
+    // two group bodies per kernel instance have to exist
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = (CINP >= 16) ? CINP / 16 : 1;
     const unsigned long long ts_pro = SRX_STAMP();
@@ -333,8 +343,9 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m_first + i * m_step) + li;
-        valid[i] = (t < npx) & (cb < a.Cout);
-        const int tt = (t < npx) ? t : 0;
+        const bool live = (t < npx) & (i < n_active);
+        valid[i] = live & (cb < a.Cout);
+        const int tt = live ? t : 0;
         const int orow = fdiv_small(tt, inv_tw, tw);
         const int ocol = tt - orow * tw;
         laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
@@ -348,6 +359,10 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
         // Software pipeline over the KH*KW*NG k-groups: the LDS fragments of group t+1 are requested
         // before the MFMAs of group t are issued.
         constexpr int NBLK = KH * KW * NG;
+        // Everything outside the MFMA stream (staging, address set-up, epilogue) runs at raised
+        // priority: next to a partner wave that issues MFMAs back to back, priority-0 VALU / memory
+        // instructions get roughly one issue slot per MFMA period.
+        __builtin_amdgcn_s_setprio(0);
         const unsigned long long ts0 = SRX_STAMP();
         t_pro += ts0 - ts_pro;
         f32x4 cur[G], nxt[G];
@@ -375,6 +390,7 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
         }
         // MFMA results are read by VALU code next: software must cover the result latency
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_s_setprio(2);
         t_mfma += SRX_STAMP() - ts0;
     } else {
 #pragma unroll
@@ -414,6 +430,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 #ifdef SRX_TRACE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
+    __builtin_amdgcn_s_setprio(2);
 
     // ---- stationary weights: wr[tap][j], k index of lane = channel ci(j, kq)
     float wr[TAPS * KSPT];
@@ -475,7 +492,9 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
         const int cnt = (n_sub - part + NPART - 1) / NPART;  // subtiles of this wave
         const float inv_tw = 1.0f / (float)tw;
         if (cnt > 0) {
-            // instances with an aux operand also hold its prefetched registers: 3 accumulators per group
+            // instances with an aux operand also hold its prefetched registers: 3 accumulators per group.
+            // Two bodies only (MAXG and MAXG-1; smaller groups run the small body with dummy sub-tiles):
+            // code size matters, see act_transcendental4.
             constexpr int MAXG = AUX ? 3 : 4;
             const int ng = (cnt + MAXG - 1) / MAXG;
             const int base = cnt / ng, rem = cnt % ng;
@@ -483,14 +502,10 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
             for (int gi = 0; gi < ng; ++gi) {
                 const int gs = base + (gi < rem ? 1 : 0);
                 const int m_first = part + idx * NPART;
-                if (MAXG >= 4 && gs == 4)
-                    conv_group<KH, KW, CINP, (MAXG >= 4 ? 4 : 1), (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
-                else if (gs == 3)
-                    conv_group<KH, KW, CINP, 3, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
-                else if (gs == 2)
-                    conv_group<KH, KW, CINP, 2, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
+                if (gs == MAXG)
+                    conv_group<KH, KW, CINP, MAXG, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, gs, li, kq, cout0, t_mfma, t_pro, t_epi);
                 else
-                    conv_group<KH, KW, CINP, 1, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, li, kq, cout0, t_mfma, t_pro, t_epi);
+                    conv_group<KH, KW, CINP, MAXG - 1, (MINW < 2), AUX>(lds, wr, bias4, a, n, h, ow0, th, tw, inv_tw, m_first, NPART, gs, li, kq, cout0, t_mfma, t_pro, t_epi);
                 idx += gs;
             }
         }
@@ -665,6 +680,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
     const bool co_ok = co < a.Cout;
     const int co_c = co_ok ? co : a.Cout - 1;   // clamped: columns >= Cout are never written out
 
+    __builtin_amdgcn_s_setprio(2);   // see conv_group: only the MFMA stream runs at priority 0
     // per-lane LDS offset (floats) of the tap/channel this lane feeds for each of its q's
     int toff[QW];
 #pragma unroll
@@ -746,6 +762,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
         ring[0] = read_x(cur, 0);
         if (LA == 2) ring[1] = read_x(cur, 1);
 
+        __builtin_amdgcn_s_setprio(0);
         for (int s0 = 0; s0 < nsteps; s0 += 3) {
 #pragma unroll
             for (int uu = 0; uu < 3; ++uu) {
@@ -766,6 +783,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(2);
         u += th;
     }
 

@@ -41,8 +41,10 @@ __device__ __forceinline__ int s2d_src(int oo, int W, int rC, int r, float inv_r
     return dy * (W * rC) + w * rC + j;
 }
 
-// chunk = RB blocks (chunk_floats = RB*B, a multiple of 4 except possibly the last chunk)
-template <bool INVERSE>
+// chunk = RB blocks (chunk_floats = RB*B, a multiple of 4).  Every chunk undergoes the SAME
+// permutation, so a thread computes the LDS gather indices of its (at most KMAX) output float4s once
+// and then only moves data: coalesced 16-B loads -> LDS -> 4 scalar LDS reads -> coalesced 16-B store.
+template <bool INVERSE, int KMAX>
 __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            size_t total, int B, int chunk_floats, int W, int rC,
                                                            int r) {
@@ -50,36 +52,51 @@ __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restri
     const float inv_B = 1.0f / (float)B;
     const float inv_a = INVERSE ? 1.0f / (float)(r * rC) : 1.0f / (float)(W * rC);
     const float inv_rC = 1.0f / (float)rC;
+    auto src_of = [&](int o) -> int {
+        int blk = (int)(((float)o + 0.5f) * inv_B);
+        blk -= (blk * B > o);
+        blk += ((blk + 1) * B <= o);
+        const int oo = o - blk * B;
+        return blk * B + (INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC));
+    };
+    const int c4 = chunk_floats >> 2;
+    int sidx[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = k * 256 + threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sidx[k][e] = (i < c4) ? src_of(4 * i + e) : 0;
+    }
     for (size_t c0 = (size_t)blockIdx.x * chunk_floats; c0 < total; c0 += (size_t)gridDim.x * chunk_floats) {
         const int n = (int)((total - c0 < (size_t)chunk_floats) ? (total - c0) : (size_t)chunk_floats);
         const int n4 = n >> 2;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n4; i += 256)
-            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(in + c0)[i];
+        const f32x4* gin = reinterpret_cast<const f32x4*>(in + c0);
+        f32x4* gout = reinterpret_cast<f32x4*>(out + c0);
+        f32x4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) v[k] = __builtin_nontemporal_load(gin + i);   // streamed once: keep it out of L2
+        }
+        __syncthreads();   // previous chunk's gathers are done
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) reinterpret_cast<f32x4*>(lds)[i] = v[k];
+        }
         for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) lds[i] = in[c0 + i];
         __syncthreads();
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = 4 * i + e;
-                int blk = (int)(((float)o + 0.5f) * inv_B);
-                blk -= (blk * B > o);
-                blk += ((blk + 1) * B <= o);
-                const int oo = o - blk * B;
-                const int src = INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC);
-                v[e] = lds[blk * B + src];
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = lds[sidx[k][e]];
+                __builtin_nontemporal_store(o, gout + i);
             }
-            reinterpret_cast<f32x4*>(out + c0)[i] = v;
         }
-        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) {
-            int blk = (int)(((float)o + 0.5f) * inv_B);
-            blk -= (blk * B > o);
-            blk += ((blk + 1) * B <= o);
-            const int oo = o - blk * B;
-            const int src = INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC);
-            out[c0 + o] = lds[blk * B + src];
-        }
+        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) out[c0 + o] = lds[src_of(o)];
     }
 }
 
@@ -108,16 +125,23 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
     size_t RB = 4;
     if (B % 4 == 0) RB = 1; else if (B % 2 == 0) RB = 2;
     if (RB * B * 4 <= lds_cap && B < (1u << 20)) {
-        while (2 * RB * B * 4 <= 24 * 1024) RB *= 2;   // ~16-24 KiB chunks: >= 6 workgroups per CU
+        while (2 * RB * B * 4 <= 24 * 1024) RB *= 2;   // ~16-24 KiB chunks: several workgroups per CU
         const int chunk = (int)(RB * B);
         size_t nchunks = (total + chunk - 1) / chunk;
-        int grid = (int)(nchunks < 4096 ? nchunks : 4096);
-        if (inverse)
-            hipLaunchKernelGGL(subpixel_lds_kernel<true>, dim3(grid), dim3(256), chunk * 4, s, in, out, total, (int)B,
-                               chunk, W, rC, r);
-        else
-            hipLaunchKernelGGL(subpixel_lds_kernel<false>, dim3(grid), dim3(256), chunk * 4, s, in, out, total, (int)B,
-                               chunk, W, rC, r);
+        // persistent workgroups: the index precomputation is paid once per workgroup
+        int grid = (int)(nchunks < 2048 ? nchunks : 2048);
+        const int kneed = (chunk / 4 + 255) / 256;
+#define SRX_SUBPIXEL_LAUNCH(K)                                                                                   \
+        if (inverse)                                                                                             \
+            hipLaunchKernelGGL((subpixel_lds_kernel<true, K>), dim3(grid), dim3(256), chunk * 4, s, in, out,    \
+                               total, (int)B, chunk, W, rC, r);                                                  \
+        else                                                                                                     \
+            hipLaunchKernelGGL((subpixel_lds_kernel<false, K>), dim3(grid), dim3(256), chunk * 4, s, in, out,   \
+                               total, (int)B, chunk, W, rC, r);
+        if (kneed <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
+        else if (kneed <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
+        else { SRX_SUBPIXEL_LAUNCH(12) }
+#undef SRX_SUBPIXEL_LAUNCH
     } else {
         if (B >= (1u << 22)) return hipErrorInvalidValue;
         size_t nb = (total + 255) / 256;
