@@ -64,6 +64,12 @@ typedef struct {
 const char* srx_version(void);
 const char* srx_last_error(void);
 
+/* Selects the forward / dgrad kernel family for layers with >= 16 input channels:
+ *   0 (default)  two persistent workgroups per CU, one LDS tile each;
+ *   1            one workgroup per CU, double-buffered LDS tile, next tile staged in the MFMA shadow.
+ * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
+int srx_set_conv_path(int pipelined);
+
 /* Bytes of caller-owned workspace an op needs (0 for FWD / BWD_DATA). */
 size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op);
 

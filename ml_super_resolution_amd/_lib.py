@@ -20,7 +20,7 @@ PAD_BY_NAME = {'same': PAD_SAME, 'valid': PAD_VALID}
 
 # every symbol include/srx.h declares
 EXPORTS = [
-    'srx_version', 'srx_last_error', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
+    'srx_version', 'srx_last_error', 'srx_set_conv_path', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
     'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_act_bwd', 'srx_depth_to_space',
     'srx_space_to_depth', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
     'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_saturate_u8', 'srx_affine',
@@ -55,6 +55,7 @@ def lib():
     dp = ctypes.POINTER(ConvDesc)
     L.srx_version.restype = ctypes.c_char_p
     L.srx_last_error.restype = ctypes.c_char_p
+    L.srx_set_conv_path.argtypes = [i]
     L.srx_conv2d_workspace_bytes.argtypes = [dp, i]
     L.srx_conv2d_workspace_bytes.restype = sz
     L.srx_reduce_scratch_bytes.restype = sz

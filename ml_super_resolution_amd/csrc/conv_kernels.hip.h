@@ -42,6 +42,7 @@ struct ConvArgs {
     int stagger;          // s_sleep(127) count for the second resident workgroup (0 = off)
     int dbg;              // diagnostic timing knobs (SRX_DBG): 1 = stage only the first tile, 2 = no stores
     unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
+    int buf_floats;       // pipelined kernel: floats per LDS tile buffer (two buffers)
 };
 
 struct WgradArgs {
@@ -211,6 +212,16 @@ __device__ __attribute__((noinline)) f32x4 act_transcendental4(f32x4 v, int act)
 __device__ __forceinline__ f32x4 act_apply4(f32x4 v, int act, float slope) {
     if (act == ACT_TANH || act == ACT_SIGMOID) {
         v = act_transcendental4(v, act);
+    } else if (act == ACT_RELU) {
+        // relu as integer ops (x & ~(x >> 31)): fp32 VALU instructions share the datapath the fp32 MFMA
+        // runs on and cost it issue time; integer ones do not.  Negative inputs (and -0) give +0.
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = v[e];                 // (bit_cast straight on a vector element miscompiles)
+            const int b = __float_as_int(f);
+            v[e] = __int_as_float(b & ~(b >> 31));
+        }
+    } else if (act == ACT_NONE) {
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
@@ -316,6 +327,63 @@ __device__ __forceinline__ void mfma_block(f32x4 (&c)[4], float w0, float w1, fl
         asm volatile(SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(3, 4, 20) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(3, 5, 21) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18) SRX_MFMA(3, 6, 22) SRX_MFMA(0, 7, 11) SRX_MFMA(1, 7, 15) SRX_MFMA(2, 7, 19) SRX_MFMA(3, 7, 23)
                      : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
                      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]), "v"(b[3][0]), "v"(b[3][1]), "v"(b[3][2]), "v"(b[3][3]));
+}
+
+// Same blocks with the stationary weights in ACCUMULATION registers ("a"): the one-wave-per-SIMD
+// kernel owns the whole 512-entry register file, keeps its 144+ weights in AGPRs (MFMA reads A/B
+// operands from either file) and leaves the 256 VGPRs to everything else.  "memory" clobber: the
+// staging loads / LDS writes placed between blocks must stay there.
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block_a(f32x4 (&c)[1], float w0, float w1, float w2, float w3, const f32x4 (&b)[1]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 1, 5) SRX_MFMA(0, 2, 6) SRX_MFMA(0, 3, 7) SRX_MFMA(0, 4, 8)
+                     : "+v"(c[0])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3])
+                     : "memory");
+    else
+        asm volatile(SRX_MFMA(0, 1, 5) SRX_MFMA(0, 2, 6) SRX_MFMA(0, 3, 7) SRX_MFMA(0, 4, 8)
+                     : "+v"(c[0])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3])
+                     : "memory");
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block_a(f32x4 (&c)[2], float w0, float w1, float w2, float w3, const f32x4 (&b)[2]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 2, 6) SRX_MFMA(1, 2, 10) SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13)
+                     : "+v"(c[0]), "+v"(c[1])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3])
+                     : "memory");
+    else
+        asm volatile(SRX_MFMA(0, 2, 6) SRX_MFMA(1, 2, 10) SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13)
+                     : "+v"(c[0]), "+v"(c[1])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3])
+                     : "memory");
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block_a(f32x4 (&c)[3], float w0, float w1, float w2, float w3, const f32x4 (&b)[3]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(2, 3, 15) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3])
+                     : "memory");
+    else
+        asm volatile(SRX_MFMA(0, 3, 7) SRX_MFMA(1, 3, 11) SRX_MFMA(2, 3, 15) SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3])
+                     : "memory");
+}
+template <bool GUARD>
+__device__ __forceinline__ void mfma_block_a(f32x4 (&c)[4], float w0, float w1, float w2, float w3, const f32x4 (&b)[4]) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\t" SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(3, 4, 20) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(3, 5, 21) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18) SRX_MFMA(3, 6, 22) SRX_MFMA(0, 7, 11) SRX_MFMA(1, 7, 15) SRX_MFMA(2, 7, 19) SRX_MFMA(3, 7, 23)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]), "v"(b[3][0]), "v"(b[3][1]), "v"(b[3][2]), "v"(b[3][3])
+                     : "memory");
+    else
+        asm volatile(SRX_MFMA(0, 4, 8) SRX_MFMA(1, 4, 12) SRX_MFMA(2, 4, 16) SRX_MFMA(3, 4, 20) SRX_MFMA(0, 5, 9) SRX_MFMA(1, 5, 13) SRX_MFMA(2, 5, 17) SRX_MFMA(3, 5, 21) SRX_MFMA(0, 6, 10) SRX_MFMA(1, 6, 14) SRX_MFMA(2, 6, 18) SRX_MFMA(3, 6, 22) SRX_MFMA(0, 7, 11) SRX_MFMA(1, 7, 15) SRX_MFMA(2, 7, 19) SRX_MFMA(3, 7, 23)
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                     : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][1]), "v"(b[2][2]), "v"(b[2][3]), "v"(b[3][0]), "v"(b[3][1]), "v"(b[3][2]), "v"(b[3][3])
+                     : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,6 +586,348 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
         tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_mfma; tr[3] = t_stage;
         tr[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);   // HW_ID[15:0]
         tr[5] = rt_entry; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = t_entry;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-wave-per-SIMD pipelined forward / dgrad (the main path for >= 16 input channels).
+//
+// Measured on gfx950 (scripts/coissue_ubench.hip, scripts/shadow_ubench.hip): a wave that streams
+// v_mfma_f32_16x16x4_f32 back to back starves the OTHER wave on its SIMD completely (VALU, LDS and
+// VMEM probes all finish only after the MFMA wave does; s_setprio does not help), so two resident
+// workgroups cannot hide each other's staging.  Within ONE wave, integer VALU / memory instructions
+// issued between its own MFMAs are almost free.  Hence: one 4-wave workgroup per CU, the input tile
+// double-buffered in LDS (2 x 80 KiB), and the NEXT tile's staging (address math, global loads, LDS
+// writes) threaded through the MFMA blocks of the CURRENT tile.
+// ---------------------------------------------------------------------------------------------
+// Staging cursor of one thread over the NEXT tile's slots s = sp, sp+PPP, sp+2*PPP, ...  Everything is
+// incremental 32-bit integer arithmetic (integer VALU is what hides in an fp32-MFMA shadow), and the
+// load is a bounds-checked buffer load: an out-of-image slot is given an out-of-range offset and the
+// hardware returns zeros, so the zero padding needs no select and no branch.
+template <int CINP>
+struct StageCtx {
+    __amdgpu_buffer_rsrc_t rsrc;  // the next tile's image, H*W*Cin*4 bytes
+    int H, W, RS, n_need;
+    int h_in0, w_in0;
+    int step_bytes, wrap_bytes;   // PPP*Cin*4 ; (W-RS)*Cin*4
+    int pass, n_pass;             // wave-uniform: next pass to issue, number of passes the tile needs
+    int s, r, c;                  // next slot of this thread and its (row, col) in the tile
+    int voff;                     // byte offset of that slot's 16 B in the image (may be negative: padding)
+    int loff;                     // float index of that slot's 16 B in the LDS buffer
+    bool active;                  // there is a next tile and its channel count allows 16-B loads
+    bool ch_ok;                   // this thread's 4 channels exist (else it writes the zero padding up to CINP)
+};
+
+template <int CINP>
+__device__ __forceinline__ void stage_begin(StageCtx<CINP>& sc, const float* xn, int H, int W, int Cin, int h_in0,
+                                            int w_in0, int RS, float inv_rs, int n_need, int sp, int c4, bool active) {
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int PPP = 256 / (CINP / 4);
+    sc.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, H * W * Cin * 4, 0x00020000);
+    sc.H = H; sc.W = W; sc.RS = RS; sc.n_need = n_need; sc.h_in0 = h_in0; sc.w_in0 = w_in0;
+    sc.step_bytes = PPP * Cin * 4;
+    sc.wrap_bytes = (W - RS) * Cin * 4;
+    sc.pass = 0;
+    sc.n_pass = active ? (n_need + PPP - 1) / PPP : 0;
+    sc.s = sp;
+    sc.r = fdiv_small(sp, inv_rs, RS);
+    sc.c = sp - sc.r * RS;
+    sc.voff = (((h_in0 + sc.r) * W + w_in0 + sc.c) * Cin + 4 * c4) * 4;
+    sc.loff = sp * PS + 4 * c4;
+    sc.active = active;
+    sc.ch_ok = 4 * c4 < Cin;
+}
+
+// issue the load of the cursor's slot
+template <int CINP>
+__device__ __forceinline__ f32x4 stage_issue(const StageCtx<CINP>& sc) {
+    const int ih = sc.h_in0 + sc.r, iw = sc.w_in0 + sc.c;
+    const bool ok = ((unsigned)ih < (unsigned)sc.H) & ((unsigned)iw < (unsigned)sc.W) & (sc.s < sc.n_need) & sc.active & sc.ch_ok;
+    const int off = ok ? sc.voff : 0x7fffffff;   // beyond num_records -> the load returns 0
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sc.rsrc, off, 0, 0));
+}
+
+// write a previously loaded slot (the one `back` passes behind the cursor) to the LDS buffer, then nothing else
+template <int CINP>
+__device__ __forceinline__ void stage_commit(const StageCtx<CINP>& sc, float* lnxt, int back, const f32x4 v) {
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int PPP = 256 / (CINP / 4);
+    const int s = sc.s - back * PPP;
+    if (sc.active && s < sc.n_need) *reinterpret_cast<f32x4*>(lnxt + sc.loff - back * PPP * PS) = v;
+}
+
+template <int CINP>
+__device__ __forceinline__ void stage_advance(StageCtx<CINP>& sc) {
+    // one wrap at most: the kernel enables shadow staging only when RS >= PPP
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int PPP = 256 / (CINP / 4);
+    sc.pass += 1;
+    sc.s += PPP; sc.loff += PPP * PS;
+    const int c1 = sc.c + PPP;
+    const bool wrap = c1 >= sc.RS;
+    sc.c = wrap ? c1 - sc.RS : c1;
+    sc.r += wrap ? 1 : 0;
+    sc.voff += sc.step_bytes + (wrap ? sc.wrap_bytes : 0);
+}
+
+// single MFMA statements for the pipelined kernel: weights from AGPRs; "memory" keeps the staging
+// loads / LDS accesses that are threaded between them in place
+#ifdef SRX_EXP_NOMEM
+#define SRX_MEMCLOB
+#else
+#define SRX_MEMCLOB : "memory"
+#endif
+__device__ __forceinline__ void mfma1_a(f32x4& c, float w, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(b) SRX_MEMCLOB);
+}
+__device__ __forceinline__ void mfma1_a_guard(f32x4& c, float w, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(b) : "memory");
+}
+// zero-cost ordering fence: code that uses x afterwards cannot be scheduled above this point, code that
+// produced x cannot sink below it (volatile asm statements keep their relative order)
+#define SRX_PIN(x) asm volatile("" : "+v"(x))
+
+template <int KH, int KW, int CINP, int G, bool AUX>
+__device__ __forceinline__ void conv_group_pipe(const float* lds, float* lnxt, const float (&wr)[KH * KW * (CINP / 4)],
+                                                const f32x4 bias4, const ConvArgs& a, StageCtx<CINP>& sc, int n, int h,
+                                                int ow0, int th, int tw, float inv_tw, int m_first, int m_step,
+                                                int n_active, int li, int kq, int cout0, int sp, int c4,
+                                                unsigned long long (&tt)[4]) {
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int NG = CINP / 16;
+    constexpr int NBLK = KH * KW * NG;
+    const unsigned long long ts_p = SRX_STAMP();
+#ifdef SRX_EXP_NOST
+    constexpr int NST = 0;
+#else
+    constexpr int NST = (NBLK / 2 < 6) ? NBLK / 2 : 6;   // staging passes threaded through this group
+#endif
+    const int npx = th * tw;
+    const int cb = cout0 + 4 * kq;
+    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+    const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;
+    int laddr[G];
+    unsigned off[G];
+    bool valid[G];
+    f32x4 acc[G];
+    // pixel (row, col) of this lane in the group's first sub-tile by one division; the following sub-tiles
+    // (stride 16*m_step pixels) by integer add-and-wrap when a single wrap suffices
+    const int t0 = 16 * m_first + li;
+    int orow = fdiv_small(t0 < npx ? t0 : 0, inv_tw, tw);
+    int ocol = (t0 < npx ? t0 : 0) - orow * tw;
+    const int dstep = 16 * m_step;
+    const bool inc_ok = dstep <= tw;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = t0 + i * dstep;
+        const bool live = (t < npx) & (i < n_active);
+        valid[i] = live & (cb < a.Cout);
+        if (i > 0) {
+            if (inc_ok) {
+                const int c1 = ocol + dstep;
+                const bool wrap = c1 >= tw;
+                ocol = wrap ? c1 - tw : c1;
+                orow += wrap ? 1 : 0;
+            } else {
+                const int tt = t < npx ? t : 0;
+                orow = fdiv_small(tt, inv_tw, tw);
+                ocol = tt - orow * tw;
+            }
+        }
+        const int prow = live ? orow : 0, pcol = live ? ocol : 0;
+        laddr[i] = (prow * a.RS + pcol) * PS + 4 * kq;
+        off[i] = valid[i] ? (unsigned)(((h + prow) * a.OW + ow0 + pcol) * a.Cout + cb) : 0u;
+        acc[i] = bias4;
+    }
+    f32x4 aux[G];
+    conv_prefetch_aux<G, AUX>(aux, off, a, img_base, vec);
+    const int row_stride = a.RS * PS;
+
+    f32x4 stg[NST > 0 ? NST : 1];
+    f32x4 cur[G], nxt[G];
+    const int pass_base = sc.pass;
+    const unsigned long long ts_m = SRX_STAMP();
+    tt[0] += ts_m - ts_p;
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i]);
+    // Per block (one tap x 16 input channels) ONE asm statement of 4G MFMAs: every extra instruction in
+    // this stream costs MFMA issue time (about 3 cycles each, measured), and separate statements make the
+    // compiler re-emit an s_waitcnt per statement.  Between blocks: the LDS reads of the next block and,
+    // in blocks 0..NST-1 / NBLK/2..NBLK/2+NST-1, one lean staging slot (issue / LDS write) for the next tile.
+#pragma unroll
+    for (int t = 0; t < NBLK; ++t) {
+        if (t + 1 < NBLK) {
+            const int t1 = t + 1;
+            const int kh1 = (t1 / NG) / KW, kw1 = (t1 / NG) % KW, g1 = t1 % NG;
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                nxt[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i] + kh1 * row_stride + kw1 * PS + 16 * g1);
+        }
+        // (wave-uniform tests: passes beyond the tile's last one cost nothing)
+        if (NST > 0 && t < NST && pass_base + t < sc.n_pass) {
+            stg[t % (NST > 0 ? NST : 1)] = stage_issue<CINP>(sc);
+            stage_advance<CINP>(sc);
+        }
+        if (NST > 0 && t >= NBLK / 2 && t < NBLK / 2 + NST) {
+            const int j = t - NBLK / 2;
+            if (pass_base + j < sc.n_pass)
+                stage_commit<CINP>(sc, lnxt, sc.pass - (pass_base + j), stg[j % (NST > 0 ? NST : 1)]);
+        }
+        const int tap = t / NG, g = t % NG;
+        const int wb = tap * (CINP / 4) + 4 * g;
+        if (t == 0)
+            mfma_block_a<true>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+        else
+            mfma_block_a<false>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+#pragma unroll
+        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const unsigned long long ts_e = SRX_STAMP();
+    tt[1] += ts_e - ts_m;
+    conv_epilogue<G, AUX>(acc, aux, valid, off, a, img_base, cb, vec);
+    tt[2] += SRX_STAMP() - ts_e;
+}
+
+template <int KH, int KW, int CINP, int NCH, bool WT, bool AUX>
+__global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TAPS = KH * KW;
+    constexpr int KSPT = CINP / 4;
+    constexpr int NPART = 4 / NCH;
+    constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, part = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int c4 = tid % TPP, sp = tid / TPP;
+
+#ifdef SRX_TRACE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    float wr[TAPS * KSPT];
+    {
+        const int co = cout0 + li;
+        const bool co_ok = co < a.Cout;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+            for (int j = 0; j < KSPT; ++j) {
+                const int ci = 16 * (j / 4) + 4 * kq + (j % 4);
+                const bool ok = co_ok & (ci < a.Cin);
+                const unsigned idx = !WT ? (unsigned)((tap * a.Cin + ci) * a.Cout + co)
+                                         : (unsigned)(((TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci);
+                const float v = a.w[ok ? idx : 0u];
+                wr[tap * KSPT + j] = ok ? v : 0.f;
+            }
+        }
+        // all loads are in flight; now move the weights into the accumulation-register file for good: they
+        // are defined as "a" values here and only ever consumed by "a" operands of the MFMA blocks.
+        // (One asm per weight right after its own load would serialise 144 global-load round trips.)
+#pragma unroll
+        for (int i = 0; i < TAPS * KSPT; ++i) {
+            float t = wr[i];
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(wr[i]) : "v"(t));
+        }
+    }
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cout0 + 4 * kq + e < a.Cout) bias4[e] = a.bias[cout0 + 4 * kq + e];
+    }
+
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    if (u0 >= u1) return;
+    const int buf_floats = a.buf_floats;
+    const bool vec_in = (a.Cin & 3) == 0;
+
+    // tile descriptor of unit u (wave-uniform)
+    auto tile_of = [&](int u, int& n, int& h, int& th, int& ow0, int& tw) {
+        h = u % a.OH;
+        const int t = u / a.OH;
+        const int tx = t % a.NTX;
+        n = t / a.NTX;
+        th = a.TH;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - u < th) th = u1 - u;
+        ow0 = tx * a.TW;
+        tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
+    };
+
+    unsigned long long tt[4] = {0, 0, 0, 0};   // trace: group prologue, MFMA+shadow section, epilogue, drain+barrier
+    int n, h, th, ow0, tw;
+    tile_of(u0, n, h, th, ow0, tw);
+    const unsigned long long t_begin = SRX_STAMP();
+    stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs,
+                     (th + KH - 1) * a.RS + (KW - 1), tid);
+    lds_barrier();
+    const unsigned long long t_first = SRX_STAMP();
+
+    int cur = 0;
+    int u = u0;
+    while (u < u1) {
+        tile_of(u, n, h, th, ow0, tw);
+        const int un = u + th;
+        const bool has_next = un < u1;
+        int n2 = n, h2 = h, th2 = th, ow02 = ow0, tw2 = tw;
+        if (has_next) tile_of(un, n2, h2, th2, ow02, tw2);
+        StageCtx<CINP> sc;
+        stage_begin<CINP>(sc, a.x + (size_t)n2 * a.H * a.W * a.Cin, a.H, a.W, a.Cin, h2 - a.pad_t, ow02 - a.pad_l, a.RS,
+                          a.inv_rs, (th2 + KH - 1) * a.RS + (KW - 1), sp, c4, has_next && vec_in && a.RS >= PPP && !(a.dbg & 4));
+        const float* lcur = lds + cur * buf_floats;
+        float* lnxt = lds + (cur ^ 1) * buf_floats;
+
+        const int n_sub = (th * tw + 15) >> 4;
+        const int cnt = (n_sub - part + NPART - 1) / NPART;
+        const float inv_tw = 1.0f / (float)tw;
+        if (cnt > 0) {
+            constexpr int MAXG = AUX ? 3 : 4;
+            const int ng = (cnt + MAXG - 1) / MAXG;
+            const int base = cnt / ng, rem = cnt % ng;
+            int idx = 0;
+            for (int gi = 0; gi < ng; ++gi) {
+                const int gs = base + (gi < rem ? 1 : 0);
+                const int m_first = part + idx * NPART;
+                if (gs == MAXG)
+                    conv_group_pipe<KH, KW, CINP, MAXG, AUX>(lcur, lnxt, wr, bias4, a, sc, n, h, ow0, th, tw, inv_tw, m_first,
+                                                             NPART, gs, li, kq, cout0, sp, c4, tt);
+                else
+                    conv_group_pipe<KH, KW, CINP, MAXG - 1, AUX>(lcur, lnxt, wr, bias4, a, sc, n, h, ow0, th, tw, inv_tw,
+                                                                 m_first, NPART, gs, li, kq, cout0, sp, c4, tt);
+                idx += gs;
+            }
+        }
+        // drain: whatever part of the next tile the groups did not cover (short tiles, ragged channels)
+        const unsigned long long ts_d = SRX_STAMP();
+        if (has_next) {
+            if (vec_in && a.RS >= PPP && !(a.dbg & 4)) {
+                while (sc.pass < sc.n_pass) {
+                    const f32x4 v = stage_issue<CINP>(sc);
+                    stage_advance<CINP>(sc);
+                    stage_commit<CINP>(sc, lnxt, 1, v);
+                }
+            } else {
+                stage_tile<CINP>(lnxt, a.x, n2, a.H, a.W, a.Cin, h2 - a.pad_t, ow02 - a.pad_l, a.RS, a.inv_rs, sc.n_need, tid);
+            }
+        }
+        lds_barrier();
+        tt[3] += SRX_STAMP() - ts_d;
+        cur ^= 1;
+        u = un;
+    }
+#ifdef SRX_TRACE
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = tt[1]; tr[3] = tt[3];
+        tr[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+        tr[5] = rt_entry; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = t_entry;
+        tr[8] = t_first - t_begin; tr[9] = 0; tr[10] = tt[0]; tr[11] = tt[2];
     }
 #endif
 }

@@ -15,6 +15,8 @@ bool launch_conv_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds
 bool launch_conv_k3c32(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_conv_c4(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_conv_misc(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_pipe_other(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 
@@ -37,6 +39,15 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
             *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW, true>, a, grid, lds, s); \
         else                                                                                              \
             *err = launch_with_lds(conv_mfma_kernel<KH, KW, CINP, NCH, WT, MINW, false>, a, grid, lds, s);\
+        return true;                                                                                      \
+    }
+// Pipelined one-wave-per-SIMD kernel (>= 16 input channels): one workgroup per CU, two LDS buffers.
+#define SRX_PIPE_CASE(KH, KW, CINP, NCH, WT)                                                              \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt == WT) {                       \
+        if (a.skip || a.mask)                                                                             \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, WT, true>, a, grid, lds, s);       \
+        else                                                                                              \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, WT, false>, a, grid, lds, s);      \
         return true;                                                                                      \
     }
 #define SRX_WGRAD_CASE(KH, KW, CINP, NCH, MINW)                                                           \

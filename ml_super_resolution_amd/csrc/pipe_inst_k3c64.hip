@@ -1,0 +1,13 @@
+// Pipelined (one wave per SIMD) 3x3, 64 input channels: the VDSR / EnhanceNet body.
+#include "launchers.h"
+namespace srx {
+bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
+    SRX_PIPE_CASE(3, 3, 64, 4, false)
+    SRX_PIPE_CASE(3, 3, 64, 4, true)
+    SRX_PIPE_CASE(3, 3, 64, 2, false)
+    SRX_PIPE_CASE(3, 3, 64, 2, true)
+    SRX_PIPE_CASE(3, 3, 64, 1, false)
+    SRX_PIPE_CASE(3, 3, 64, 1, true)
+    return false;
+}
+}  // namespace srx

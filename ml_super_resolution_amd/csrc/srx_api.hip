@@ -15,6 +15,7 @@ using namespace srx;
 namespace {
 
 thread_local char g_err[512] = "";
+int g_use_pipe = -1;   // conv kernel family, see srx_set_conv_path
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -28,6 +29,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr size_t kLdsBudget = 80 * 1024 - 320;  // two workgroups per CU (160 KiB); 320 B spare for wgrad's zero slot
 constexpr int kMaxGrid = 512;             // 2 persistent workgroups x 256 CUs
+constexpr int kPipeGrid = 256;            // pipelined kernels: 1 persistent workgroup per CU
 
 struct Plan {
     int KH, KW, cinp, nch;
@@ -125,9 +127,22 @@ size_t part_stride(const srx_conv_desc* d) {
     return (per + 3) / 4 * 4;
 }
 
-int dispatch_conv(const Plan& p, bool wt, const ConvArgs& a, hipStream_t s) {
+int dispatch_conv(const Plan& p, bool wt, const ConvArgs& a_in, hipStream_t s) {
     ConvKey k{p.KH, p.KW, p.cinp, p.nch, wt};
     hipError_t err = hipSuccess;
+    ConvArgs a = a_in;
+    // Main path for >= 16 input channels: the pipelined one-wave-per-SIMD kernel, one workgroup per
+    // CU with two LDS tile buffers.  SRX_PIPE=0 selects the older two-workgroups-per-CU kernels (A/B).
+    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 0; }
+    if (g_use_pipe && p.cinp >= 16) {
+        const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+        a.buf_floats = (int)(p.lds_bytes / 4);
+        if (launch_pipe_k3c64(k, a, pgrid, 2 * p.lds_bytes, s, &err) ||
+            launch_pipe_other(k, a, pgrid, 2 * p.lds_bytes, s, &err)) {
+            if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+            return SRX_OK;
+        }
+    }
     bool hit = launch_conv_k3c64(k, a, p.grid, p.lds_bytes, s, &err) ||
                launch_conv_k3c32(k, a, p.grid, p.lds_bytes, s, &err) ||
                launch_conv_c4(k, a, p.grid, p.lds_bytes, s, &err) ||
@@ -174,6 +189,12 @@ extern "C" {
 
 const char* srx_version(void) { return "srx 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 const char* srx_last_error(void) { return g_err; }
+int srx_set_conv_path(int pipelined) {
+    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 0; }
+    const int old = g_use_pipe;
+    g_use_pipe = pipelined ? 1 : 0;
+    return old;
+}
 size_t srx_reduce_scratch_bytes(void) { return (size_t)kReduceBlocks * sizeof(float); }
 
 size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op) {

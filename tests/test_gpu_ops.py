@@ -34,8 +34,17 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=[0, 1], ids=['two_wg_per_cu', 'pipelined'])
+def conv_path(request):
+    """Run a test under both forward/dgrad kernel families (srx_set_conv_path)."""
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(request.param)
+    yield request.param
+    _lib.lib().srx_set_conv_path(old)
+
+
 @pytest.mark.parametrize('case', OP_CASES, ids=[c[0] for c in OP_CASES])
-def test_golden_ops(case, golden_ops, ops):
+def test_golden_ops(case, golden_ops, ops, conv_path):
     name, k, cin, cout, pad, act, H, W = case
     g = {key.split('.', 1)[1]: golden_ops[key] for key in golden_ops.files if key.startswith(name + '.')}
     x, w, b = dev(g['x']), dev(g['w']), dev(g['b'])
@@ -71,7 +80,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=['%dx%dx%d_k%d_%d-%d_%s' % s[:7] for s in SHAPES])
-def test_conv_fwd_bwd_vs_oracle(shape, ops):
+def test_conv_fwd_bwd_vs_oracle(shape, ops, conv_path):
     N, H, W, k, cin, cout, pad, act = shape
     rng = np.random.default_rng(abs(hash(shape)) % (1 << 31))
     x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
@@ -96,7 +105,7 @@ def test_conv_fwd_bwd_vs_oracle(shape, ops):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-def test_conv_skip_and_post_relu(ops):
+def test_conv_skip_and_post_relu(ops, conv_path):
     rng = np.random.default_rng(7)
     x = rng.uniform(-1, 1, (2, 19, 23, 64)).astype(np.float32)
     w = rng.normal(0, 0.05, (3, 3, 64, 64)).astype(np.float32)

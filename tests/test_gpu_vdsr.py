@@ -92,6 +92,28 @@ def test_momentum_clip_path(built, golden_nets):
     assert m.stack.global_step == 1
 
 
+def test_kernel_families_agree_bit_for_bit():
+    """The two forward/dgrad kernel families (srx_set_conv_path) compute every output element with the
+    same fp32 operation order: identical bits, so switching is purely a tuning decision."""
+    from ml_super_resolution_amd import _lib
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    m = model_vdsr.VdsrModel(num_layers=20, use_adam=True, seed=9)
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    hd = torch.rand((16, 41, 41, 3), device='cuda', generator=gen) * 2 - 1
+    sd = (hd + 0.1 * torch.randn((16, 41, 41, 3), device='cuda', generator=gen)).clamp(-1, 1)
+    outs = []
+    for path in (0, 1):
+        old = _lib.lib().srx_set_conv_path(path)
+        try:
+            m.stack.forward(sd, keep=True)
+            m.stack.loss_and_backward(hd)
+            outs.append((m.stack.acts[-1].clone(), m.stack.grads.clone()))
+        finally:
+            _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_full_size_batch_properties():
     """BASELINE config 3 shape (256x41x41): size-independent properties -- batch elements are
     independent (a shard of the batch gives the same rows), determinism, gradient additivity."""
