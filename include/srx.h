@@ -70,7 +70,9 @@ const char* srx_last_error(void);
  * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
 int srx_set_conv_path(int pipelined);
 
-/* Bytes of caller-owned workspace an op needs (0 for FWD / BWD_DATA). */
+/* Bytes of caller-owned workspace an op uses.  BWD_FILTER: required (per-workgroup partials).
+ * FWD / BWD_DATA: optional 256 bytes holding the tile counter of dynamic scheduling; with ws == NULL
+ * those ops fall back to a static work split (same results, a few per cent slower at large sizes). */
 size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op);
 
 /* y = act(bias + x (*) w) [+ skip] [relu]

@@ -43,6 +43,9 @@ struct ConvArgs {
     int dbg;              // diagnostic timing knobs (SRX_DBG): 1 = stage only the first tile, 2 = no stores
     unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
     int buf_floats;       // pipelined kernel: floats per LDS tile buffer (two buffers)
+    int* tile_counter;    // dynamic scheduling (two-workgroup kernels): next tile to hand out, preset to gridDim.x; null = static
+    int tiles_total, tiles_per_col;   // N*NTX*tiles_per_col tiles of TH rows (the last of a column may be shorter)
+    int lds_sched_slot;   // float index in LDS of the 4-byte mailbox used to broadcast the tile index
 };
 
 struct WgradArgs {
@@ -532,30 +535,49 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     if (a.stagger) stagger_second_workgroup(a.stagger);
     unsigned long long t_mfma = 0, t_stage = 0, t_bar1 = 0, t_load = 0, t_pro = 0, t_epi = 0;
     const unsigned long long t_begin = SRX_STAMP();
+    // Work distribution.  Static: a contiguous range of output rows per workgroup.  Dynamic (tile_counter
+    // set): fixed tiles of TH rows handed out through one atomic counter -- the wave that an fp32-MFMA
+    // partner starves falls behind, and a static split then leaves one workgroup per CU idle at the end.
+    // Which workgroup computes a tile never changes a result.
+    const bool dyn = a.tile_counter != nullptr;
     int u = u0;
-    while (u < u1) {
-        const int h = u % a.OH;
-        const int t = u / a.OH;
-        const int tx = t % a.NTX;
-        const int n = t / a.NTX;
-        int th = a.TH;
-        if (a.OH - h < th) th = a.OH - h;
-        if (u1 - u < th) th = u1 - u;
+    int tile = blockIdx.x;             // dynamic mode: the first tile is the workgroup's own index
+    int* mailbox = reinterpret_cast<int*>(lds + a.lds_sched_slot);
+    while (dyn ? (tile < a.tiles_total) : (u < u1)) {
+        int h, n, tx, th;
+        if (dyn) {
+            const int ti = tile % a.tiles_per_col;
+            const int t = tile / a.tiles_per_col;
+            tx = t % a.NTX;
+            n = t / a.NTX;
+            h = ti * a.TH;
+            th = (a.OH - h < a.TH) ? (a.OH - h) : a.TH;
+        } else {
+            h = u % a.OH;
+            const int t = u / a.OH;
+            tx = t % a.NTX;
+            n = t / a.NTX;
+            th = a.TH;
+            if (a.OH - h < th) th = a.OH - h;
+            if (u1 - u < th) th = u1 - u;
+        }
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
         const int n_need = (th + KH - 1) * a.RS + (KW - 1);
+        const bool first_tile = dyn ? (tile == (int)blockIdx.x) : (u == u0);
 
         const unsigned long long ts_stage = SRX_STAMP();
         lds_barrier();
         const unsigned long long ts_b1 = SRX_STAMP();
-        if (!(a.dbg & 1) || u == u0)
+        if (dyn && tid == 0) *mailbox = atomicAdd(a.tile_counter, 1);     // the NEXT tile, fetched early
+        if (!(a.dbg & 1) || first_tile)
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
         const unsigned long long ts_ld = SRX_STAMP();
         lds_barrier();
+        const int next_tile = dyn ? *mailbox : 0;
         t_stage += SRX_STAMP() - ts_stage;
         t_bar1 += ts_b1 - ts_stage;
         t_load += ts_ld - ts_b1;
-
         const int n_sub = (th * tw + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;  // subtiles of this wave
         const float inv_tw = 1.0f / (float)tw;
@@ -578,6 +600,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
             }
         }
         u += th;
+        tile = next_tile;
     }
 #ifdef SRX_TRACE
     if (a.trace && lane == 0) {

@@ -39,6 +39,17 @@ def out_shape(d):
 
 
 _scratch = {}
+_sched_ws = {}
+
+
+def sched_workspace(device):
+    """256 bytes per (device, stream) lent to forward / dgrad launches for their dynamic tile counter."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _sched_ws.get(key)
+    if t is None:
+        t = torch.zeros(64, dtype=torch.int32, device=device)
+        _sched_ws[key] = t
+    return t
 
 
 def reduce_scratch(device):
@@ -54,8 +65,9 @@ def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_re
         _chk(t, n)
     d = conv_desc(x.shape, w.shape, padding, act, post_add_relu)
     y = out if out is not None else torch.empty(out_shape(d), dtype=torch.float32, device=x.device)
-    check(lib().srx_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(skip), _ptr(y), None, 0,
-                               _stream()), 'srx_conv2d_fwd')
+    ws = sched_workspace(x.device)
+    check(lib().srx_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(skip), _ptr(y),
+                               ctypes.c_void_p(ws.data_ptr()), 256, _stream()), 'srx_conv2d_fwd')
     return y
 
 
@@ -65,8 +77,9 @@ def conv2d_bwd_data(dpre, w, x_shape, padding='same', x_in=None, in_act=None, ou
         _chk(t, n)
     d = conv_desc(x_shape, w.shape, padding)
     dx = out if out is not None else torch.empty(tuple(x_shape), dtype=torch.float32, device=dpre.device)
+    ws = sched_workspace(dpre.device)
     check(lib().srx_conv2d_bwd_data(ctypes.byref(d), _ptr(dpre), _ptr(w), _ptr(x_in), ACT_BY_NAME[in_act],
-                                    _ptr(dx), None, 0, _stream()), 'srx_conv2d_bwd_data')
+                                    _ptr(dx), ctypes.c_void_p(ws.data_ptr()), 256, _stream()), 'srx_conv2d_bwd_data')
     return dx
 
 

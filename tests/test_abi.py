@@ -30,7 +30,7 @@ def test_descriptor_validation_without_gpu():
     d = _lib.ConvDesc(256, 41, 41, 64, 64, 3, 3, 1, 0, 1, 0, 0)
     ws = L.srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_BWD_FILTER)
     assert ws > 0 and ws % 4 == 0
-    assert L.srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_FWD) == 0
+    assert L.srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_FWD) == 256     # optional tile counter
     bad = _lib.ConvDesc(256, 41, 41, 64, 64, 3, 3, 2, 0, 1, 0, 0)          # stride 2
     assert L.srx_conv2d_workspace_bytes(ctypes.byref(bad), _lib.OP_BWD_FILTER) == 0
     assert b'stride' in L.srx_last_error()
