@@ -125,6 +125,9 @@ int main() {
     sustained("16x16x4 4acc 2w/SIMD", k16<4, false>, 512, iters, 8 * 4 * 4 * 2048.0, 3.0);
     sustained("16x16x4 4acc +ds_read 2w/SIMD", k16<4, true>, 512, iters, 8 * 4 * 4 * 2048.0, 3.0);
     sustained("32x32x2 4acc 2w/SIMD", k32<4>, 512, iters, 8 * 4 * 4096.0, 3.0);
+    // the conv kernels' LDS read density: one ds_read_b128 per 4 MFMAs (1 accumulator per read here)
+    sustained("16x16x4 1acc +ds_read/4MFMA 2w/SIMD", k16<1, true>, 512, iters, 8 * 4 * 1 * 2048.0, 3.0);
+    sustained("16x16x4 1acc no LDS 2w/SIMD", k16<1, false>, 512, iters, 8 * 4 * 1 * 2048.0, 3.0);
     // per wave per iter: 8 u * 4 s * NACC MFMAs * 2048 flop
     run("16x16x4 4acc 1wave/SIMD", k16<4, false>, 256, iters, 8 * 4 * 4 * 2048.0);
     run("16x16x4 4acc 2waves/SIMD", k16<4, false>, 512, iters, 8 * 4 * 4 * 2048.0);
