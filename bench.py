@@ -90,8 +90,10 @@ def main():
                          '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev            # (rehearsals may put several gloo ranks on one GPU)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
 
     from ml_super_resolution_amd.vdsr import model_vdsr
     from ml_super_resolution_amd import dist as srx_dist
@@ -128,7 +130,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        nccl = torch.distributed.get_backend() == 'nccl'
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if nccl else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

@@ -22,7 +22,8 @@ def init_process_group(rank=None, world_size=None, local_rank=None, backend=None
     os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # SRX_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box); RCCL needs one GPU per rank
+        backend = os.environ.get('SRX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if not td.is_initialized():
         td.init_process_group(backend=backend, rank=rank, world_size=world_size)
     return backend
@@ -32,6 +33,10 @@ def allreduce_mean_(flat, world_size):
     """In-place average of a flat gradient buffer over all ranks: one collective."""
     if td.get_backend() == 'nccl':
         td.all_reduce(flat, op=td.ReduceOp.AVG)
+    elif flat.is_cuda:                      # gloo rehearsal with device tensors: reduce through the host
+        host = flat.detach().cpu()
+        td.all_reduce(host, op=td.ReduceOp.SUM)
+        flat.copy_(host.div_(world_size))
     else:                                   # gloo has no AVG
         td.all_reduce(flat, op=td.ReduceOp.SUM)
         flat.div_(world_size)
@@ -40,7 +45,12 @@ def allreduce_mean_(flat, world_size):
 
 def attach(stack, world_size):
     """Install the gradient all-reduce on a ConvStack and make the replicas start identical."""
-    td.broadcast(stack.params, src=0)
+    if td.get_backend() != 'nccl' and stack.params.is_cuda:
+        host = stack.params.detach().cpu()
+        td.broadcast(host, src=0)
+        stack.params.copy_(host)
+    else:
+        td.broadcast(stack.params, src=0)
     stack.grad_hook = lambda g: allreduce_mean_(g, world_size)
     return stack
 
