@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // PROBE: 0 none, 1 dependent VALU chain, 2 independent VALU, 3 ds_read_b128 loop, 4 global_load loop,
 //        5 integer address math (v_mul_lo, cvt) mix
-template <int PROBE, bool MFMA_ON, int PRIO>
+template <int PROBE, bool MFMA_ON, int PRIO, int YIELD = 0>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsigned long long* st, int mfma_iters,
                                            int probe_iters) {
     __shared__ __attribute__((aligned(16))) float lds[4096];
@@ -29,9 +29,15 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsig
             c0 = __builtin_amdgcn_s_memtime();
             for (int it = 0; it < mfma_iters; ++it) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 8; ++u) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, acc[i], 0, 0, 0);
+                    if (YIELD == 1 && (u & 3) == 3) asm volatile("s_nop 15");
+                    if (YIELD == 2 && (u & 3) == 3) asm volatile("s_sleep 1");
+                    if (YIELD == 3 && (u & 1) == 1) asm volatile("s_nop 7");
+                    if (YIELD == 4 && u == 7) asm volatile("s_sleep 1");
+                    if (YIELD == 5 && (u & 3) == 3) asm volatile("s_nop 15\n\ts_nop 15");
+                }
             }
             c1 = __builtin_amdgcn_s_memtime();
             res = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
@@ -126,5 +132,13 @@ int main() {
     run("int addr math alone", k<5, false, 0>, 0, PI, 4);
     run("int addr math + MFMA partner", k<5, true, 0>, MI, PI, 4);
     run("int addr math + MFMA partner, prio 3", k<5, true, 3>, MI, PI, 4);
+    run("indep VALU + MFMA(yield s_nop15/16)", k<2, true, 0, 1>, MI, PI, 16);
+    run("indep VALU + MFMA(yield s_sleep1/16)", k<2, true, 0, 2>, MI, PI, 16);
+    run("indep VALU + MFMA(yield s_nop7/8)", k<2, true, 0, 3>, MI, PI, 16);
+    run("indep VALU + MFMA(yield s_sleep1/32)", k<2, true, 0, 4>, MI, PI, 16);
+    run("indep VALU + MFMA(yield 2x s_nop15/16)", k<2, true, 0, 5>, MI, PI, 16);
+    run("int addr math + MFMA(yield s_sleep1/16)", k<5, true, 0, 2>, MI, PI, 4);
+    run("global_load + MFMA(yield s_sleep1/16)", k<4, true, 0, 2>, MI, PI, 16);
+    run("ds_read + MFMA(yield s_sleep1/16)", k<3, true, 0, 2>, MI, PI, 16);
     return 0;
 }
