@@ -172,6 +172,16 @@ int srx_rownorm_loss_fwd_bwd(const float* pred, const float* target, size_t rows
 int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val,
              srx_stream_t stream);
 
+/* tf.image.ssim(a, b, max_val) per image (TF-1.8 defaults: 11x11 gaussian window sigma 1.5, k1 .01,
+ * k2 .03, VALID windows, mean over positions then channels):
+ *   out[n] = mean_c mean_{oh,ow} [ (2 mu_a mu_b + c1)/(mu_a^2 + mu_b^2 + c1) *
+ *                                  (2 cov_ab + c2)/(var_a + var_b + c2) ],  c_i = (k_i max_val)^2
+ * a, b: [N,H,W,C] with H, W >= 11.  scratch: >= srx_ssim_scratch_bytes(N) bytes.
+ * vdsr/vdsr/experiment_evaluate.py:57-60, vdsr/vdsr/experiment_resolve.py, espcn/espcn/experiment_test.py:55. */
+int srx_ssim(const float* a, const float* b, float* out, int N, int H, int W, int C, float max_val,
+             void* scratch, srx_stream_t stream);
+size_t srx_ssim_scratch_bytes(int N);
+
 /* tf.saturate_cast(x*127.5+127.5, uint8): clamp to [0,255], truncate.
  * vdsr/vdsr/experiment_resolve.py:65-69, espcn/espcn/experiment_train.py:58. */
 int srx_saturate_u8(const float* x, uint8_t* out, size_t numel, srx_stream_t stream);

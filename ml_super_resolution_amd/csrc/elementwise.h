@@ -16,6 +16,9 @@ hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float
                            hipStream_t s);
 hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t rows, size_t row_len, float* loss,
                                float* dpred, float* norms, hipStream_t s);
+size_t ssim_scratch_bytes(int N);
+hipError_t launch_ssim(const float* a, const float* b, float* out, int N, int H, int W, int C, float max_val, float* scratch,
+                       hipStream_t s);
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s);
 hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b, hipStream_t s);
 hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s);

@@ -404,6 +404,80 @@ hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t ro
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// SSIM (tf.image.ssim semantics).  One thread per output position and channel evaluates the 11x11
+// gaussian-weighted moments directly; evaluation-only code, HBM/L2-bound at image sizes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSsimBlocks = 128;   // partial sums per image
+
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           int H, int W, int C, float c1, float c2,
+                                                           float* __restrict__ partial) {
+    __shared__ float sh[4];
+    __shared__ float g[11];
+    if (threadIdx.x < 11) {
+        float sum = 0.f;
+        for (int i = 0; i < 11; ++i) sum += __expf(-(float)((i - 5) * (i - 5)) / (2.0f * 1.5f * 1.5f));
+        const int d = (int)threadIdx.x - 5;
+        g[threadIdx.x] = __expf(-(float)(d * d) / (2.0f * 1.5f * 1.5f)) / sum;
+    }
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int OH = H - 10, OW = W - 10;
+    const size_t total = (size_t)OH * OW * C;
+    const float* pa = a + (size_t)n * H * W * C;
+    const float* pb = b + (size_t)n * H * W * C;
+    float acc = 0.f;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const size_t t = o / C;
+        const int ow = (int)(t % OW), oh = (int)(t / OW);
+        float ma = 0.f, mb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+        for (int i = 0; i < 11; ++i) {
+            const float* ra = pa + ((size_t)(oh + i) * W + ow) * C + c;
+            const float* rb = pb + ((size_t)(oh + i) * W + ow) * C + c;
+            float xa = 0.f, xb = 0.f, xaa = 0.f, xbb = 0.f, xab = 0.f;
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                const float va = ra[(size_t)j * C], vb = rb[(size_t)j * C], w = g[j];
+                xa += w * va; xb += w * vb; xaa += w * va * va; xbb += w * vb * vb; xab += w * va * vb;
+            }
+            const float wi = g[i];
+            ma += wi * xa; mb += wi * xb; saa += wi * xaa; sbb += wi * xbb; sab += wi * xab;
+        }
+        // TF's _ssim_per_channel: luminance * contrast-structure
+        const float num0 = 2.0f * ma * mb, den0 = ma * ma + mb * mb;
+        const float lum = (num0 + c1) / (den0 + c1);
+        const float cs = (2.0f * sab - num0 + c2) / (saa + sbb - den0 + c2);
+        acc += lum * cs;
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(size_t)n * kSsimBlocks + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(128) void ssim_finish_kernel(const float* __restrict__ partial, float inv_count,
+                                                          float* __restrict__ out) {
+    __shared__ double sh[128];
+    sh[threadIdx.x] = (threadIdx.x < kSsimBlocks) ? (double)partial[(size_t)blockIdx.x * kSsimBlocks + threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] * (double)inv_count);
+}
+
+size_t ssim_scratch_bytes(int N) { return (size_t)(N > 0 ? N : 0) * kSsimBlocks * sizeof(float); }
+
+hipError_t launch_ssim(const float* a, const float* b, float* out, int N, int H, int W, int C, float max_val,
+                       float* scratch, hipStream_t s) {
+    const float c1 = (0.01f * max_val) * (0.01f * max_val), c2 = (0.03f * max_val) * (0.03f * max_val);
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3(kSsimBlocks, N), dim3(256), 0, s, a, b, H, W, C, c1, c2, scratch);
+    const double count = (double)(H - 10) * (W - 10) * C;
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(N), dim3(128), 0, s, scratch, (float)(1.0 / count), out);
+    return hipGetLastError();
+}
+
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s) {
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, y, dpre, n, act);
     return hipGetLastError();

@@ -392,6 +392,16 @@ int srx_psnr(const float* a, const float* b, float* out, int N, size_t per_image
     SRX_CHECK_LAUNCH(launch_psnr(a, b, out, N, per_image, max_val, (hipStream_t)stream), "psnr");
 }
 
+size_t srx_ssim_scratch_bytes(int N) { return ssim_scratch_bytes(N); }
+
+int srx_ssim(const float* a, const float* b, float* out, int N, int H, int W, int C, float max_val, void* scratch,
+             srx_stream_t stream) {
+    if (!a || !b || !out || !scratch) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || C <= 0 || H < 11 || W < 11) return fail(SRX_ERR_BAD_ARG, "ssim needs N, C > 0 and H, W >= 11 (11x11 windows)");
+    if (N > 65535) return fail(SRX_ERR_UNSUPPORTED, "ssim: more than 65535 images per call");
+    SRX_CHECK_LAUNCH(launch_ssim(a, b, out, N, H, W, C, max_val, (float*)scratch, (hipStream_t)stream), "ssim");
+}
+
 int srx_saturate_u8(const float* x, uint8_t* out, size_t numel, srx_stream_t stream) {
     if (!x || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
     if (numel == 0) return SRX_OK;

@@ -48,10 +48,11 @@ def prepare_image_pair(hr_image, upscaling_factor):
     return lr.astype(np.float32), space_to_depth_numpy(hr, upscaling_factor).astype(np.float32)
 
 
-def psnr_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
-    """experiment_test.py:32-54: map to [0,1], clip, optionally keep only Y of rgb_to_yuv
-    (0.299, 0.587, 0.114), PSNR with max_val 1.  PSNR is permutation invariant, so it is evaluated
-    directly in sub-pixel space as the reference does."""
+def scores_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
+    """experiment_test.py:32-55: map to [0,1], clip, optionally reshape [h,w,3r^2] -> [h,w*r^2,3] and keep
+    only Y of rgb_to_yuv (0.299, 0.587, 0.114); PSNR and SSIM with max_val 1, both evaluated in that
+    sub-pixel arrangement exactly as the reference does (PSNR is permutation invariant; SSIM is not, and the
+    reference's numbers are of this arrangement).  Returns (psnr[N], ssim[N])."""
     sr = ops.affine(sr_results, 0.5, 0.5).clamp_(0.0, 1.0)
     hr = ops.affine(hr_targets, 0.5, 0.5).clamp_(0.0, 1.0)
     if score_space == 'y':
@@ -59,7 +60,11 @@ def psnr_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
         wts = torch.tensor([0.299, 0.587, 0.114], device=sr.device)
         sr = (sr.reshape(n, h, w * (d // 3), 3) * wts).sum(-1, keepdim=True).contiguous()
         hr = (hr.reshape(n, h, w * (d // 3), 3) * wts).sum(-1, keepdim=True).contiguous()
-    return ops.psnr(hr, sr, 1.0)
+    return ops.psnr(hr, sr, 1.0), ops.ssim(hr, sr, 1.0)
+
+
+def psnr_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
+    return scores_in_subpixel_space(model, sr_results, hr_targets, score_space)[0]
 
 
 def super_resolve_array(model, lr_image):
@@ -85,16 +90,18 @@ def evaluate_images(FLAGS):
     model = build_model(FLAGS)
     m = model['_model']
     names = [n for n in sorted(os.listdir(FLAGS.data_path)) if n[-4:] in ['.png', '.jpg', '.bmp']]
-    psnrs = []
+    psnrs, ssims = [], []
     for name in names:
         hr_image = np.asarray(Image.open(os.path.join(FLAGS.data_path, name)).convert('RGB'))
         lr, hr = prepare_image_pair(hr_image, model['scaling_factor'])
         sr = m.forward(torch.from_numpy(lr[None]).to(m.stack.device))
-        p = psnr_in_subpixel_space(model, sr, torch.from_numpy(hr[None]).to(m.stack.device), FLAGS.score_space)
+        p, q = scores_in_subpixel_space(model, sr, torch.from_numpy(hr[None]).to(m.stack.device), FLAGS.score_space)
         psnrs.append(float(p[0]))
-        print('name: {:>32}, psnr: {:.4f}'.format(name, psnrs[-1]))
+        ssims.append(float(q[0]))
+        print('name: {:>32}, psnr: {:.4f}, ssim: {:.4f}'.format(name, psnrs[-1], ssims[-1]))
     print('data: {}'.format(FLAGS.data_path))
     print('psnr: {0:.4f}'.format(float(np.mean(psnrs))))
+    print('ssim: {0:.4f}'.format(float(np.mean(ssims))))
 
 
 def main():

@@ -194,6 +194,16 @@ def psnr(a, b, max_val):
     return out
 
 
+def ssim(a, b, max_val):
+    """tf.image.ssim(a, b, max_val) per image: [N,H,W,C] x2 -> [N]."""
+    _chk(a, 'a'); _chk(b, 'b')
+    N, H, W, C = a.shape
+    out = torch.empty((N,), dtype=torch.float32, device=a.device)
+    scratch = torch.empty(lib().srx_ssim_scratch_bytes(N) // 4, dtype=torch.float32, device=a.device)
+    check(lib().srx_ssim(_ptr(a), _ptr(b), _ptr(out), N, H, W, C, float(max_val), _ptr(scratch), _stream()), 'srx_ssim')
+    return out
+
+
 def saturate_u8(x):
     _chk(x, 'x')
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)

@@ -1,8 +1,7 @@
 """
 experiment_evaluate.py -- mirror of vdsr/vdsr/experiment_evaluate.py: mean PSNR of (sd, sr) against
-hd over a directory of images and the mean forward time per image (:64-123).  PSNR uses max_val 2.0
-on [-1,1] images as the reference does (:57-60).  SSIM (tf.image.ssim) is listed as a "next" row
- and is not computed here.
+hd over a directory of images and the mean forward time per image (:64-123).  PSNR and SSIM use
+max_val 2.0 on [-1,1] images as the reference does (:57-60); both are computed on the GPU.
 
   python -m ml_super_resolution_amd.vdsr.experiment_evaluate --ckpt_path model.ckpt-25600.pt \
          --hd_image_dir_path Set5 --scaling_factor 2
@@ -38,7 +37,7 @@ def main(argv=None):
     model = model_vdsr.VdsrModel(FLAGS.num_layers, device=device)
     model.stack.load_state_dict(torch.load(FLAGS.ckpt_path))
     names = [n for n in sorted(os.listdir(FLAGS.hd_image_dir_path)) if n[-4:] in ['.png', '.jpg', '.bmp']]
-    sd_psnrs, sr_psnrs, total = [], [], 0.0
+    sd_psnrs, sr_psnrs, sd_ssims, sr_ssims, total = [], [], [], [], 0.0
     for n in names:
         sd_np, hd_np = load_image(os.path.join(FLAGS.hd_image_dir_path, n), FLAGS.scaling_factor)
         sd, hd = torch.from_numpy(sd_np).to(device), torch.from_numpy(hd_np).to(device)
@@ -49,9 +48,12 @@ def main(argv=None):
         total += time.time() - t0
         sd_psnrs.append(ops.psnr(hd, sd, 2.0).item())
         sr_psnrs.append(ops.psnr(hd, sr, 2.0).item())
+        sd_ssims.append(ops.ssim(hd, sd, 2.0).item())
+        sr_ssims.append(ops.ssim(hd, sr, 2.0).item())
     print('x{}'.format(FLAGS.scaling_factor))
     print('time (s)     : {}'.format(total / max(len(names), 1)))
     print('psnr (sd, sr): {}, {}'.format(np.mean(sd_psnrs), np.mean(sr_psnrs)))
+    print('ssim (sd, sr): {}, {}'.format(np.mean(sd_ssims), np.mean(sr_ssims)))
 
 
 if __name__ == '__main__':

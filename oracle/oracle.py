@@ -235,6 +235,35 @@ def psnr(a, b, max_val):
     return 20.0 * np.log10(max_val) - 10.0 * np.log10(mse)
 
 
+def ssim(a, b, max_val, filter_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """tf.image.ssim (TF 1.8 image_ops_impl._ssim_per_channel): gaussian window from _fspecial_gauss,
+    VALID depthwise filtering, luminance * contrast-structure, mean over positions then channels.
+    vdsr/vdsr/experiment_evaluate.py:57-60; espcn/espcn/experiment_test.py:55.  Parity unpinned (TF absent)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    coords = np.arange(filter_size) - (filter_size - 1) / 2.0
+    g = np.exp(-coords ** 2 / (2.0 * sigma ** 2))
+    g = g / g.sum()
+    win = np.outer(g, g)
+
+    def reducer(x):
+        N, H, W, C = x.shape
+        OH, OW = H - filter_size + 1, W - filter_size + 1
+        out = np.zeros((N, OH, OW, C))
+        for i in range(filter_size):
+            for j in range(filter_size):
+                out += win[i, j] * x[:, i:i + OH, j:j + OW, :]
+        return out
+
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    mean0, mean1 = reducer(a), reducer(b)
+    num0, den0 = mean0 * mean1 * 2.0, mean0 ** 2 + mean1 ** 2
+    lum = (num0 + c1) / (den0 + c1)
+    num1, den1 = reducer(a * b) * 2.0, reducer(a * a + b * b)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(axis=(1, 2)).mean(axis=-1)
+
+
 def saturate_u8(x):
     """tf.saturate_cast(x*127.5+127.5, uint8): clamp then truncate.
     vdsr/vdsr/experiment_resolve.py:65-69."""

@@ -148,3 +148,27 @@ def test_espcn_srcnn_golden(golden_nets):
     y = O.srcnn_forward(g['srcnn.lo'], srcnn_params(107))
     assert y.shape == (1, 21, 21, 3)
     np.testing.assert_allclose(y, g['srcnn.y'], rtol=1e-5, atol=1e-6)
+
+
+def test_ssim_restatement_properties_and_cross_check():
+    """tf.image.ssim restatement: identity -> 1, symmetry, decreases with noise, and agreement with an
+    independent depthwise-conv formulation in torch (fp64)."""
+    rng = np.random.default_rng(13)
+    a = rng.uniform(-1, 1, (2, 23, 31, 3))
+    b = np.clip(a + 0.2 * rng.normal(size=a.shape), -1, 1)
+    c = np.clip(a + 0.6 * rng.normal(size=a.shape), -1, 1)
+    np.testing.assert_allclose(O.ssim(a, a, 2.0), 1.0, atol=1e-12)
+    np.testing.assert_allclose(O.ssim(a, b, 2.0), O.ssim(b, a, 2.0), rtol=1e-12)
+    assert (O.ssim(a, b, 2.0) > O.ssim(a, c, 2.0)).all()
+    # independent formulation: depthwise conv2d with the normalised outer-product gaussian
+    x = torch.arange(11, dtype=torch.float64) - 5
+    g = torch.exp(-x ** 2 / (2 * 1.5 ** 2)); g = g / g.sum()
+    w = torch.outer(g, g)[None, None].repeat(3, 1, 1, 1)
+    ta, tb = (torch.from_numpy(v).permute(0, 3, 1, 2) for v in (a, b))
+    f = lambda z: torch.nn.functional.conv2d(z, w, groups=3)
+    mu_a, mu_b = f(ta), f(tb)
+    c1, c2 = (0.01 * 2.0) ** 2, (0.03 * 2.0) ** 2
+    lum = (2 * mu_a * mu_b + c1) / (mu_a ** 2 + mu_b ** 2 + c1)
+    cs = (2 * (f(ta * tb) - mu_a * mu_b) + c2) / (f(ta * ta) - mu_a ** 2 + f(tb * tb) - mu_b ** 2 + c2)
+    ref = (lum * cs).mean(dim=(2, 3)).mean(dim=1).numpy()
+    np.testing.assert_allclose(O.ssim(a, b, 2.0), ref, rtol=1e-10)
