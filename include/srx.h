@@ -190,6 +190,22 @@ int srx_saturate_u8(const float* x, uint8_t* out, size_t numel, srx_stream_t str
  * (espcn/espcn/experiment_test.py:160,179). */
 int srx_affine(const float* x, float* out, size_t numel, float a, float b, srx_stream_t stream);
 
+/* ---- "next" row N1: on-device low-resolution synthesis (vdsr/vdsr/dataset.py:13-38,95-115) ---- */
+
+/* skimage.util.img_as_float32 of uint8 data: out = in / 255. */
+int srx_u8_to_unit_float(const uint8_t* in, float* out, size_t numel, srx_stream_t stream);
+
+/* skimage.filters.gaussian(image, sigma, mode='nearest') on [N,H,W,C] (channels are not blurred):
+ * separable 1-D kernels of radius int(4*sigma + 0.5), weights exp(-x^2/(2 sigma^2)) normalised, borders
+ * replicated (scipy.ndimage.gaussian_filter, truncate 4.0).  tmp: N*H*W*C floats.  sigma <= 0 copies. */
+int srx_gaussian_blur(const float* in, float* out, float* tmp, int N, int H, int W, int C, float sigma,
+                      srx_stream_t stream);
+
+/* skimage.transform.resize(image, [OH, OW], mode='edge', anti_aliasing=False) with order 1: bilinear
+ * sampling at in = (out + 0.5) * (H / OH) - 0.5, coordinates clamped to the image.  [N,H,W,C] -> [N,OH,OW,C]. */
+int srx_resize_bilinear(const float* in, float* out, int N, int H, int W, int C, int OH, int OW,
+                        srx_stream_t stream);
+
 /* tf.image.resize_nearest_neighbor by an integer factor (pixel replication):
  * in [N,H,W,C] -> out [N,H*f,W*f,C].  enet/enet/model_enet.py:78-80. */
 int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f,

@@ -19,6 +19,9 @@ hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t ro
 size_t ssim_scratch_bytes(int N);
 hipError_t launch_ssim(const float* a, const float* b, float* out, int N, int H, int W, int C, float max_val, float* scratch,
                        hipStream_t s);
+hipError_t launch_u8_to_float(const uint8_t* in, float* out, size_t n, hipStream_t s);
+hipError_t launch_gaussian_blur(const float* in, float* out, float* tmp, int N, int H, int W, int C, float sigma, hipStream_t s);
+hipError_t launch_resize_bilinear(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s);
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s);
 hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b, hipStream_t s);
 hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s);

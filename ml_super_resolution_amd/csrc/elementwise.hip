@@ -478,6 +478,92 @@ hipError_t launch_ssim(const float* a, const float* b, float* out, int N, int H,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// LR synthesis ("next" row N1): uint8 -> float, separable gaussian blur, bilinear resize
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void u8_to_float_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                          size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (float)in[i] / 255.0f;
+}
+
+// AXIS 0: along H, 1: along W.  Border: replicate (index clamp).
+template <int AXIS>
+__global__ __launch_bounds__(256) void gaussian_1d_kernel(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                          int H, int W, int C, float sigma, int radius) {
+    __shared__ float wts[64];
+    if (threadIdx.x <= (unsigned)radius && threadIdx.x < 64) {
+        float sum = 0.f;
+        for (int i = -radius; i <= radius; ++i) sum += expf(-0.5f * (float)(i * i) / (sigma * sigma));
+        wts[threadIdx.x] = expf(-0.5f * (float)(threadIdx.x * threadIdx.x) / (sigma * sigma)) / sum;
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        size_t t = o / C;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const size_t n = t / H;
+        const float* base = in + n * (size_t)H * W * C + c;
+        float acc = 0.f;
+        for (int i = -radius; i <= radius; ++i) {
+            int hh = h, ww = w;
+            if (AXIS == 0) { hh = h + i; hh = hh < 0 ? 0 : (hh >= H ? H - 1 : hh); }
+            else { ww = w + i; ww = ww < 0 ? 0 : (ww >= W ? W - 1 : ww); }
+            acc += wts[i < 0 ? -i : i] * base[((size_t)hh * W + ww) * C];
+        }
+        out[o] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int N, int H, int W, int C, int OH, int OW) {
+    const size_t total = (size_t)N * OH * OW * C;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        size_t t = o / C;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const size_t n = t / OH;
+        float fy = ((float)oh + 0.5f) * sy - 0.5f, fx = ((float)ow + 0.5f) * sx - 0.5f;
+        fy = fminf(fmaxf(fy, 0.f), (float)(H - 1));
+        fx = fminf(fmaxf(fx, 0.f), (float)(W - 1));
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const float* base = in + n * (size_t)H * W * C + c;
+        const float v00 = base[((size_t)y0 * W + x0) * C], v01 = base[((size_t)y0 * W + x1) * C];
+        const float v10 = base[((size_t)y1 * W + x0) * C], v11 = base[((size_t)y1 * W + x1) * C];
+        out[o] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+    }
+}
+
+hipError_t launch_u8_to_float(const uint8_t* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(u8_to_float_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_gaussian_blur(const float* in, float* out, float* tmp, int N, int H, int W, int C, float sigma,
+                                hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    if (sigma <= 0.f) return hipMemcpyAsync(out, in, total * sizeof(float), hipMemcpyDeviceToDevice, s);
+    const int radius = (int)(4.0f * sigma + 0.5f);
+    if (radius > 63) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gaussian_1d_kernel<0>, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, tmp, N, H, W, C, sigma, radius);
+    hipLaunchKernelGGL(gaussian_1d_kernel<1>, dim3(ew_grid(total, 1)), dim3(256), 0, s, tmp, out, N, H, W, C, sigma, radius);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_bilinear(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s) {
+    const size_t total = (size_t)N * OH * OW * C;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+    return hipGetLastError();
+}
+
 hipError_t launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, hipStream_t s) {
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, y, dpre, n, act);
     return hipGetLastError();

@@ -414,6 +414,27 @@ int srx_affine(const float* x, float* out, size_t numel, float a, float b, srx_s
     SRX_CHECK_LAUNCH(launch_affine(x, out, numel, a, b, (hipStream_t)stream), "affine");
 }
 
+int srx_u8_to_unit_float(const uint8_t* in, float* out, size_t numel, srx_stream_t stream) {
+    if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_u8_to_float(in, out, numel, (hipStream_t)stream), "u8_to_unit_float");
+}
+
+int srx_gaussian_blur(const float* in, float* out, float* tmp, int N, int H, int W, int C, float sigma,
+                      srx_stream_t stream) {
+    if (!in || !out || !tmp) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(SRX_ERR_BAD_ARG, "bad blur dims");
+    if (in == out || tmp == in || tmp == out) return fail(SRX_ERR_BAD_ARG, "gaussian blur buffers must be distinct");
+    if (sigma > 15.0f) return fail(SRX_ERR_UNSUPPORTED, "sigma %g: radius above 63 not supported", sigma);
+    SRX_CHECK_LAUNCH(launch_gaussian_blur(in, out, tmp, N, H, W, C, sigma, (hipStream_t)stream), "gaussian_blur");
+}
+
+int srx_resize_bilinear(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, srx_stream_t stream) {
+    if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return fail(SRX_ERR_BAD_ARG, "bad resize dims");
+    SRX_CHECK_LAUNCH(launch_resize_bilinear(in, out, N, H, W, C, OH, OW, (hipStream_t)stream), "resize_bilinear");
+}
+
 int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, srx_stream_t stream) {
     if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || f <= 0) return fail(SRX_ERR_BAD_ARG, "bad upsample dims");

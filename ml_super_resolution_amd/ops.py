@@ -218,6 +218,33 @@ def affine(x, a, b, out=None):
     return out
 
 
+def u8_to_unit_float(x):
+    """uint8 tensor -> float32 in [0,1] (skimage.util.img_as_float32)."""
+    if not x.is_cuda or x.dtype != torch.uint8 or not x.is_contiguous():
+        raise ValueError('x must be a contiguous uint8 tensor on the GPU')
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().srx_u8_to_unit_float(ctypes.c_void_p(x.data_ptr()), _ptr(out), x.numel(), _stream()), 'srx_u8_to_unit_float')
+    return out
+
+
+def gaussian_blur(x, sigma):
+    """skimage.filters.gaussian(x, sigma, mode='nearest') on [N,H,W,C]."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    check(lib().srx_gaussian_blur(_ptr(x), _ptr(out), _ptr(tmp), N, H, W, C, float(sigma), _stream()), 'srx_gaussian_blur')
+    return out
+
+
+def resize_bilinear(x, oh, ow):
+    """skimage.transform.resize(x, [oh, ow], mode='edge', anti_aliasing=False), order 1."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_resize_bilinear(_ptr(x), _ptr(out), N, H, W, C, int(oh), int(ow), _stream()), 'srx_resize_bilinear')
+    return out
+
+
 def upsample_nearest(x, f):
     _chk(x, 'x')
     N, H, W, C = x.shape

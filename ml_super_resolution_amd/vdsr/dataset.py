@@ -53,3 +53,62 @@ def hd_image_to_sd_image(hd_image, scaling_factor):
         return out
 
     return resize(resize(bl, sd_h, sd_w), hd_h, hd_w)
+
+
+def degrade_on_device(hd01, scaling_factor):
+    """dataset.py:13-38 on the GPU for a batch [N,H,W,3] of float images in [0,1]: gaussian blur
+    sigma = 0.5*(s-1) ('nearest' borders), bilinear resize to (int(H/s), int(W/s)) and back ('edge')."""
+    from .. import ops
+    N, H, W, C = hd01.shape
+    sd_h, sd_w = int(H / scaling_factor), int(W / scaling_factor)
+    bl = ops.gaussian_blur(hd01, max(0.0, 0.5 * (scaling_factor - 1.0)))
+    return ops.resize_bilinear(ops.resize_bilinear(bl, sd_h, sd_w), H, W)
+
+
+def image_batches(images_u8, scaling_factors, image_size, batch_size, device, seed=None):
+    """The reference's `image_batches` (dataset.py:41-128) with the float work moved to the GPU.
+    images_u8: list of decoded uint8 images [h,w,3] (host).  Per patch, as the reference: random crop,
+    random horizontal flip (host, uint8 slicing), then ON DEVICE: /255, degrade with a randomly chosen
+    scaling factor, map both to [-1,1].  Patches are grouped by scaling factor so that every device op runs
+    on a uniform batch.  Yields (sd_images, hd_images) device tensors [batch_size, S, S, 3]."""
+    from .. import ops
+    if not scaling_factors:
+        scaling_factors = [2.0, 3.0, 4.0]
+    if any(s <= 1 for s in scaling_factors):
+        raise Exception('invalide scaling factors')
+    rng = np.random.default_rng(seed)
+    images_u8 = [im for im in images_u8 if im.shape[0] >= image_size and im.shape[1] >= image_size and im.shape[2] == 3]
+    if not images_u8:
+        raise ValueError('no image is at least %dx%d' % (image_size, image_size))
+    order = np.arange(len(images_u8))
+    pos = len(order)
+    while True:
+        crops, factors = [], []
+        while len(crops) < batch_size:
+            if pos == len(order):
+                rng.shuffle(order)
+                pos = 0
+            im = images_u8[order[pos]]
+            pos += 1
+            h, w, _ = im.shape
+            x = rng.integers(0, max(w - image_size, 1))
+            y = rng.integers(0, max(h - image_size, 1))
+            crop = im[y:y + image_size, x:x + image_size]
+            if rng.integers(0, 2) == 1:
+                crop = crop[:, ::-1]
+            crops.append(crop)
+            factors.append(rng.choice(scaling_factors))
+        factors = np.asarray(factors)
+        idx = np.argsort(factors, kind='stable')
+        hd_u8 = torch.from_numpy(np.ascontiguousarray(np.stack(crops)[idx])).to(device)
+        hd01 = ops.u8_to_unit_float(hd_u8)
+        sd01 = torch.empty_like(hd01)
+        f_sorted = factors[idx]
+        start = 0
+        while start < batch_size:
+            end = start
+            while end < batch_size and f_sorted[end] == f_sorted[start]:
+                end += 1
+            sd01[start:end] = degrade_on_device(hd01[start:end].contiguous(), float(f_sorted[start]))
+            start = end
+        yield ops.affine(sd01, 2.0, -1.0), ops.affine(hd01, 2.0, -1.0)

@@ -71,8 +71,18 @@ def main(argv=None):
     if world > 1:
         srx_dist.attach(model.stack, world)
 
-    batches = (dataset.npz_batches(FLAGS.data_path, per_rank, device, seed=rank) if FLAGS.data_path
-               else dataset.synthetic_batches(FLAGS.image_size, per_rank, device, seed=104 + 10 * rank))
+    if FLAGS.data_path and os.path.isdir(FLAGS.data_path):
+        # the reference's data source: a directory of images; decode on the host, degrade on the GPU
+        from PIL import Image
+        import numpy as np
+        names = [n for n in sorted(os.listdir(FLAGS.data_path)) if n[-4:].lower() in ('.png', '.jpg', '.bmp', 'jpeg')]
+        images = [np.asarray(Image.open(os.path.join(FLAGS.data_path, n)).convert('RGB')) for n in names]
+        factors = [float(x) for x in str(FLAGS.scaling_factors).split('_')]
+        batches = dataset.image_batches(images, factors, FLAGS.image_size, per_rank, device, seed=rank)
+    elif FLAGS.data_path:
+        batches = dataset.npz_batches(FLAGS.data_path, per_rank, device, seed=rank)
+    else:
+        batches = dataset.synthetic_batches(FLAGS.image_size, per_rank, device, seed=104 + 10 * rank)
     log = open(os.path.join(FLAGS.logs_path, 'train.jsonl'), 'a') if (FLAGS.logs_path and rank == 0) else None
     t0 = time.time()
     while True:

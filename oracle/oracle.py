@@ -264,6 +264,41 @@ def ssim(a, b, max_val, filter_size=11, sigma=1.5, k1=0.01, k2=0.03):
     return (lum * cs).mean(axis=(1, 2)).mean(axis=-1)
 
 
+def gaussian_blur(x, sigma):
+    """skimage.filters.gaussian(image, sigma, mode='nearest') per image of [N,H,W,C]: scipy.ndimage's
+    gaussian_filter on the two spatial axes, truncate 4.0, replicated borders.
+    vdsr/vdsr/dataset.py:28; espcn/espcn/dataset.py:101.  Parity unpinned (skimage absent)."""
+    from scipy.ndimage import gaussian_filter
+    x = np.asarray(x, np.float64)
+    if sigma <= 0:
+        return x.copy()
+    return gaussian_filter(x, sigma=(0, sigma, sigma, 0), mode='nearest', truncate=4.0)
+
+
+def resize_bilinear(x, oh, ow):
+    """skimage.transform.resize(image, [oh, ow], mode='edge', anti_aliasing=False) (order 1) per image of
+    [N,H,W,C]: sample at (out + 0.5) * (in/out) - 0.5 with edge clamping.  vdsr/vdsr/dataset.py:31-35."""
+    from scipy.ndimage import map_coordinates
+    x = np.asarray(x, np.float64)
+    N, H, W, C = x.shape
+    ys = np.clip((np.arange(oh) + 0.5) * H / oh - 0.5, 0, H - 1)
+    xs = np.clip((np.arange(ow) + 0.5) * W / ow - 0.5, 0, W - 1)
+    yy, xx = np.meshgrid(ys, xs, indexing='ij')
+    out = np.empty((N, oh, ow, C))
+    for n in range(N):
+        for c in range(C):
+            out[n, :, :, c] = map_coordinates(x[n, :, :, c], [yy, xx], order=1, mode='nearest')
+    return out
+
+
+def hd_to_sd(hd01, scaling_factor):
+    """vdsr/vdsr/dataset.py:13-38 on a batch of float images in [0,1]."""
+    N, H, W, C = hd01.shape
+    sd_h, sd_w = int(H / scaling_factor), int(W / scaling_factor)
+    bl = gaussian_blur(hd01, max(0.0, 0.5 * (scaling_factor - 1.0)))
+    return resize_bilinear(resize_bilinear(bl, sd_h, sd_w), H, W)
+
+
 def saturate_u8(x):
     """tf.saturate_cast(x*127.5+127.5, uint8): clamp then truncate.
     vdsr/vdsr/experiment_resolve.py:65-69."""
