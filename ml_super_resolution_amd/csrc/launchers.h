@@ -25,10 +25,18 @@ hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, 
 
 template <typename K, typename A>
 inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hipStream_t s) {
-    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent and cheap.
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    // > 64 KiB of dynamic LDS needs the attribute.  It is raised once per kernel to the largest size the
+    // planner can ask for (160 KiB), outside any stream capture of later launches.
+    static thread_local const void* configured[64];
+    static thread_local int n_configured = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    bool known = false;
+    for (int i = 0; i < n_configured; ++i) known |= (configured[i] == fn);
+    if (!known) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (n_configured < 64) configured[n_configured++] = fn;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
