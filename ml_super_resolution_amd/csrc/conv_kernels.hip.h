@@ -389,6 +389,58 @@ __device__ __forceinline__ void mfma_block_a(f32x4 (&c)[4], float w0, float w1, 
                      : "memory");
 }
 
+// Stationary-weight fetch for one wave: wr[tap*KSPT + j] = W_eff[k = channel ci(j,kq)][cout0 + li].
+// Exact-fit layers (Cin == CINP, Cout a multiple of 16: every VDSR / EnhanceNet body layer) take a fast
+// path: the lane's part of the index is one VGPR, the (tap, j) part is wave-uniform and goes into the
+// buffer load's SGPR offset -- one instruction per weight (one b128 per 4 weights for the transposed
+// dgrad read) instead of ~10 (bounds compares, selects, 64-bit address arithmetic).
+template <int TAPS, int CINP, bool WT>
+__device__ __forceinline__ void load_stationary_weights(float (&wr)[TAPS * (CINP / 4)], const ConvArgs& a, int cout0,
+                                                        int li, int kq) {
+    constexpr int KSPT = CINP / 4;
+    const int co = cout0 + li;
+    if (CINP >= 16 && a.Cin == CINP && (a.Cout & 15) == 0 && (long)TAPS * a.Cin * a.Cout * 4 < (1L << 31)) {
+        __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, TAPS * a.Cin * a.Cout * 4, 0x00020000);
+        if (!WT) {
+            const int vlane = (4 * kq * a.Cout + co) * 4;              // bytes
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int j = 0; j < KSPT; ++j) {
+                    const int soff = ((tap * a.Cin + 16 * (j / 4) + (j % 4)) * a.Cout) * 4;   // wave-uniform
+                    wr[tap * KSPT + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vlane, soff, 0));
+                }
+        } else {
+            const int vlane = (co * a.Cin + 4 * kq) * 4;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int g = 0; g < KSPT / 4; ++g) {
+                    const int soff = (((TAPS - 1 - tap) * a.Cout) * a.Cin + 16 * g) * 4;
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vlane, soff, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wr[tap * KSPT + 4 * g + e] = v[e];
+                }
+        }
+        return;
+    }
+    // general path: branch-free, out-of-range (padded) channels read element 0 and are zeroed by a select
+    const bool co_ok = co < a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int j = 0; j < KSPT; ++j) {
+            const int ci = (CINP >= 16) ? 16 * (j / 4) + 4 * kq + (j % 4) : kq;
+            const bool ok = co_ok & (ci < a.Cin);
+            const unsigned idx = !WT ? (unsigned)((tap * a.Cin + ci) * a.Cout + co)
+                                     : (unsigned)(((TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci);
+            const float v = a.w[ok ? idx : 0u];
+            wr[tap * KSPT + j] = ok ? v : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------
@@ -505,23 +557,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 
     // ---- stationary weights: wr[tap][j], k index of lane = channel ci(j, kq)
     float wr[TAPS * KSPT];
-    {
-        // branch-free: out-of-range (padded) channels read element 0 and are zeroed by a select
-        const int co = cout0 + li;
-        const bool co_ok = co < a.Cout;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-            for (int j = 0; j < KSPT; ++j) {
-                const int ci = (CINP >= 16) ? 16 * (j / 4) + 4 * kq + (j % 4) : kq;
-                const bool ok = co_ok & (ci < a.Cin);
-                const unsigned idx = !WT ? (unsigned)((tap * a.Cin + ci) * a.Cout + co)
-                                         : (unsigned)(((TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci);
-                const float v = a.w[ok ? idx : 0u];
-                wr[tap * KSPT + j] = ok ? v : 0.f;
-            }
-        }
-    }
+    load_stationary_weights<TAPS, CINP, WT>(wr, a, cout0, li, kq);
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll
@@ -833,20 +869,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
 #endif
     float wr[TAPS * KSPT];
     {
-        const int co = cout0 + li;
-        const bool co_ok = co < a.Cout;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-            for (int j = 0; j < KSPT; ++j) {
-                const int ci = 16 * (j / 4) + 4 * kq + (j % 4);
-                const bool ok = co_ok & (ci < a.Cin);
-                const unsigned idx = !WT ? (unsigned)((tap * a.Cin + ci) * a.Cout + co)
-                                         : (unsigned)(((TAPS - 1 - tap) * a.Cout + co) * a.Cin + ci);
-                const float v = a.w[ok ? idx : 0u];
-                wr[tap * KSPT + j] = ok ? v : 0.f;
-            }
-        }
+        load_stationary_weights<TAPS, CINP, WT>(wr, a, cout0, li, kq);
         // all loads are in flight; now move the weights into the accumulation-register file for good: they
         // are defined as "a" values here and only ever consumed by "a" operands of the MFMA blocks.
         // (One asm per weight right after its own load would serialise 144 global-load round trips.)
