@@ -129,7 +129,7 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
         const int chunk = (int)(RB * B);
         size_t nchunks = (total + chunk - 1) / chunk;
         // persistent workgroups: the index precomputation is paid once per workgroup
-        int grid = (int)(nchunks < 2048 ? nchunks : 2048);
+        int grid = (int)(nchunks < 1024 ? nchunks : 1024);
         const int kneed = (chunk / 4 + 255) / 256;
 #define SRX_SUBPIXEL_LAUNCH(K)                                                                                   \
         if (inverse)                                                                                             \
