@@ -14,8 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int PROBE, bool MFMA_ON, int PRIO, int YIELD = 0>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsigned long long* st, int mfma_iters,
                                            int probe_iters) {
-    __shared__ __attribute__((aligned(16))) float lds[4096];
-    for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = (float)(i & 15) * 0.01f;
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 512) lds[i] = (float)(i & 15) * 0.01f;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -88,6 +88,58 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsig
             }
             x = (float)ia;
         }
+        if (PROBE == 6) {          // VALU-free: global loads with fixed address registers, SALU loop
+            const f32x4* gp = reinterpret_cast<const f32x4*>(gsrc) + (size_t)blockIdx.x * 4096 + lane;
+            f32x4 t0, t1, t2, t3;
+            for (int it = 0; it < probe_iters; ++it) {
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(gp) : "memory");
+            }
+            x = t0[0] + t1[0] + t2[0] + t3[0];
+        } else if (PROBE == 7) {   // VALU-free: ds_read_b128 with a fixed address register
+            const unsigned la = (unsigned)(lane * 16);
+            f32x4 t0, t1, t2, t3;
+            for (int it = 0; it < probe_iters; ++it) {
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                             "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(la) : "memory");
+            }
+            x = t0[0] + t1[0] + t2[0] + t3[0];
+        } else if (PROBE == 8) {   // VALU-free: ds_write_b128
+            const unsigned la = (unsigned)(lane * 16 + 8192);
+            f32x4 t0 = {x, y, z, q};
+            for (int it = 0; it < probe_iters; ++it) {
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %1 offset:1024\n\t"
+                             "ds_write_b128 %0, %1 offset:2048\n\tds_write_b128 %0, %1 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             :: "v"(la), "v"(t0) : "memory");
+            }
+        } else if (PROBE == 10) {  // LDS-DMA: global -> LDS directly, 4 B per lane (one 256-B pixel per wave-instruction)
+            const float* gp = gsrc + (size_t)blockIdx.x * 16384 + lane;
+            float* lbase = lds + 2048 + (wave - 4) * 1024;     // wave-uniform LDS destination
+            for (int it = 0; it < probe_iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_global_load_lds(gp + u * 64, (__attribute__((address_space(3))) void*)(lbase + u * 64), 4, 0, 0);   // loop-invariant addresses: no VALU
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (PROBE == 11) {  // LDS-DMA 16 B per lane (1 KiB per wave-instruction)
+            const float* gp = gsrc + (size_t)blockIdx.x * 16384 + lane * 4;
+            float* lbase = lds + 2048 + (wave - 4) * 1024;
+            for (int it = 0; it < probe_iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_global_load_lds(gp + u * 256, (__attribute__((address_space(3))) void*)(lbase + (u & 3) * 256), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (PROBE == 9) {   // SALU only
+            unsigned sa = 1;
+            for (int it = 0; it < probe_iters; ++it) {
+                asm volatile("s_add_u32 %0, %0, 3\n\ts_lshl_b32 %0, %0, 1\n\ts_add_u32 %0, %0, 5\n\ts_lshr_b32 %0, %0, 1" : "+s"(sa));
+            }
+            x = (float)sa;
+        }
         c1 = __builtin_amdgcn_s_memtime();
         res = x + y + z + q;
     }
@@ -132,6 +184,18 @@ int main() {
     run("int addr math alone", k<5, false, 0>, 0, PI, 4);
     run("int addr math + MFMA partner", k<5, true, 0>, MI, PI, 4);
     run("int addr math + MFMA partner, prio 3", k<5, true, 3>, MI, PI, 4);
+    run("VALU-free global_load x4 alone", k<6, false, 0>, 0, PI, 4);
+    run("VALU-free global_load x4 + MFMA partner", k<6, true, 0>, MI, PI, 4);
+    run("VALU-free ds_read_b128 x4 alone", k<7, false, 0>, 0, PI, 4);
+    run("VALU-free ds_read_b128 x4 + MFMA partner", k<7, true, 0>, MI, PI, 4);
+    run("VALU-free ds_write_b128 x4 alone", k<8, false, 0>, 0, PI, 4);
+    run("VALU-free ds_write_b128 x4 + MFMA partner", k<8, true, 0>, MI, PI, 4);
+    run("LDS-DMA dword x4 alone", k<10, false, 0>, 0, PI, 4);
+    run("LDS-DMA dword x4 + MFMA partner", k<10, true, 0>, MI, PI, 4);
+    run("LDS-DMA dwordx4 x4 alone", k<11, false, 0>, 0, PI, 4);
+    run("LDS-DMA dwordx4 x4 + MFMA partner", k<11, true, 0>, MI, PI, 4);
+    run("SALU only alone", k<9, false, 0>, 0, PI, 4);
+    run("SALU only + MFMA partner", k<9, true, 0>, MI, PI, 4);
     run("indep VALU + MFMA(yield s_nop15/16)", k<2, true, 0, 1>, MI, PI, 16);
     run("indep VALU + MFMA(yield s_sleep1/16)", k<2, true, 0, 2>, MI, PI, 16);
     run("indep VALU + MFMA(yield s_nop7/8)", k<2, true, 0, 3>, MI, PI, 16);
