@@ -11,7 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // PROBE: 0 none, 1 dependent VALU chain, 2 independent VALU, 3 ds_read_b128 loop, 4 global_load loop,
 //        5 integer address math (v_mul_lo, cvt) mix
-template <int PROBE, bool MFMA_ON, int PRIO, int YIELD = 0>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int PROBE, bool MFMA_ON, int PRIO, int YIELD = 0, int SHAPE = 16>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsigned long long* st, int mfma_iters,
                                            int probe_iters) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
@@ -22,7 +23,20 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* gsrc, unsig
     unsigned long long c0 = 0, c1 = 0;
     float res = 0.f;
     if (wave < 4) {
-        if (MFMA_ON) {
+        if (MFMA_ON && SHAPE == 32) {
+            f32x16 acc32[2];
+            for (int i = 0; i < 2; ++i) for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+            float w = 0.001f * lane, b = 0.5f;
+            c0 = __builtin_amdgcn_s_memtime();
+            for (int it = 0; it < mfma_iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc32[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, acc32[i], 0, 0, 0);
+            }
+            c1 = __builtin_amdgcn_s_memtime();
+            res = acc32[0][0] + acc32[1][5];
+        } else if (MFMA_ON) {
             f32x4 acc[4];
             for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             float w = 0.001f * lane, b = 0.5f;
@@ -190,6 +204,9 @@ int main() {
     run("VALU-free ds_read_b128 x4 + MFMA partner", k<7, true, 0>, MI, PI, 4);
     run("VALU-free ds_write_b128 x4 alone", k<8, false, 0>, 0, PI, 4);
     run("VALU-free ds_write_b128 x4 + MFMA partner", k<8, true, 0>, MI, PI, 4);
+    run("32x32x2 MFMA alone (16/iter)", k<0, true, 0, 0, 32>, MI, 0, 0);
+    run("indep VALU + 32x32x2 MFMA partner", k<2, true, 0, 0, 32>, MI, PI, 16);
+    run("VALU-free global_load + 32x32x2 partner", k<6, true, 0, 0, 32>, MI, PI, 4);
     run("LDS-DMA dword x4 alone", k<10, false, 0>, 0, PI, 4);
     run("LDS-DMA dword x4 + MFMA partner", k<10, true, 0>, MI, PI, 4);
     run("LDS-DMA dwordx4 x4 alone", k<11, false, 0>, 0, PI, 4);
