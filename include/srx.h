@@ -65,8 +65,11 @@ const char* srx_version(void);
 const char* srx_last_error(void);
 
 /* Selects the forward / dgrad kernel family for layers with >= 16 input channels:
- *   0 (default)  two persistent workgroups per CU, one LDS tile each;
- *   1            one workgroup per CU, double-buffered LDS tile, next tile staged in the MFMA shadow.
+ *   1 (default)  3x3 body layers (16..64 exact-fit input channels, full-width tiles, none / ReLU /
+ *                ReluGrad / residual epilogues) run on one workgroup per CU with a double-buffered LDS
+ *                tile, everything but the MFMAs done by scalar and memory instructions; all other shapes
+ *                use the kernels of path 0;
+ *   0            two persistent workgroups per CU, one LDS tile each, for every shape.
  * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
 int srx_set_conv_path(int pipelined);
 

@@ -650,219 +650,361 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-wave-per-SIMD pipelined forward / dgrad (the main path for >= 16 input channels).
+// One-wave-per-SIMD pipelined forward / dgrad (srx_set_conv_path(1) / SRX_PIPE=1).
 //
-// Measured on gfx950 (scripts/coissue_ubench.hip, scripts/shadow_ubench.hip): a wave that streams
-// v_mfma_f32_16x16x4_f32 back to back starves the OTHER wave on its SIMD completely (VALU, LDS and
-// VMEM probes all finish only after the MFMA wave does; s_setprio does not help), so two resident
-// workgroups cannot hide each other's staging.  Within ONE wave, integer VALU / memory instructions
-// issued between its own MFMAs are almost free.  Hence: one 4-wave workgroup per CU, the input tile
-// double-buffered in LDS (2 x 80 KiB), and the NEXT tile's staging (address math, global loads, LDS
-// writes) threaded through the MFMA blocks of the CURRENT tile.
+// What gfx950 charges a wave for instructions placed between its own fp32 MFMAs (measured,
+// scripts/shadow2_ubench.hip, shadow3_ubench.hip; an MFMA alone issues every 32 cycles):
+//     any VALU instruction (v_add, v_cndmask, v_mov, even v_nop) ...... +13 cycles for the first of a run,
+//                                                                        +8 for each further one
+//     SALU instruction ................................................ ~0 (up to ~4 per MFMA)
+//     ds_read_b128 / buffer_load / buffer_store / ds_write / s_waitcnt . ~0..3 (bandwidth permitting)
+// and a wave streaming fp32 MFMAs starves the other wave of its SIMD completely (coissue_ubench).  So
+// fp32 MFMA time and VALU time simply add up, on one wave or two, and the only lever is the NUMBER of
+// VALU instructions.  This kernel therefore keeps one 4-wave workgroup per CU (weights in AGPRs, the
+// input tile double-buffered in LDS, 2 x 80 KiB) and does everything that is not an MFMA with scalar
+// or memory instructions:
+//   * staging of the next tile: the tile is cut into passes of PPP slots inside ONE tile row, so the
+//     lane part of every address is a constant (tid*16 bytes in the image row, a constant in LDS) and
+//     the pass part is wave-uniform -> SGPR offset of a bounds-checked buffer load (rows outside the image:
+//     an out-of-range scalar offset, the hardware returns zeros), lanes outside the row: an EXEC mask
+//     set by s_mov.  0 VALU to issue a pass, 1 (LDS address) to commit it;
+//   * sub-tile LDS addresses: a table (sub-tile, lane) -> byte address kept in the 16 pad bytes of the
+//     LDS pixel slots, fetched with ds_read_b32 during the previous group;
+//   * output addresses: lane part constant, sub-tile part in the buffer resource's base / num_records
+//     (which also drops the pixels past the end of a short last sub-tile);
+//   * bias: the C operand of each accumulator's first MFMA;
+//   * the PREVIOUS group's epilogue runs inside the current group from a parked copy of its
+//     accumulators, so no s_nop covers the MFMA result latency.
 // ---------------------------------------------------------------------------------------------
-// Staging cursor of one thread over the NEXT tile's slots s = sp, sp+PPP, sp+2*PPP, ...  Everything is
-// incremental 32-bit integer arithmetic (integer VALU is what hides in an fp32-MFMA shadow), and the
-// load is a bounds-checked buffer load: an out-of-image slot is given an out-of-range offset and the
-// hardware returns zeros, so the zero padding needs no select and no branch.
-template <int CINP>
-struct StageCtx {
-    __amdgpu_buffer_rsrc_t rsrc;  // the next tile's image, H*W*Cin*4 bytes
-    int H, W, RS, n_need;
-    int h_in0, w_in0;
-    int step_bytes, wrap_bytes;   // PPP*Cin*4 ; (W-RS)*Cin*4
-    int pass, n_pass;             // wave-uniform: next pass to issue, number of passes the tile needs
-    int s, r, c;                  // next slot of this thread and its (row, col) in the tile
-    int voff;                     // byte offset of that slot's 16 B in the image (may be negative: padding)
-    int loff;                     // float index of that slot's 16 B in the LDS buffer
-    bool active;                  // there is a next tile and its channel count allows 16-B loads
-    bool ch_ok;                   // this thread's 4 channels exist (else it writes the zero padding up to CINP)
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+
+constexpr int kOobOffset = 0x7fffffff;    // lane offset beyond every buffer resource used here (host-checked < 2^31)
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct StageGeo {      // wave-uniform constants of the staging sequence
+    int JP1;           // passes per tile row, minus 1
+    int rowfix_g, rowfix_l;  // extra bytes (beyond the constant pass step) when the next pass starts a new row: image, LDS
+    unsigned long long m_first, m_last;   // EXEC masks of a row's first / last pass (pad columns / row end)
+};
+// The scalar offset is UNSIGNED to the hardware (measured: a negative one puts the whole pass out of range),
+// so the buffer resource starts pad_l pixels before the image (those bytes are never touched: the lanes
+// that would are masked) and offsets count from there.  Rows below the image need no test: their offsets
+// are beyond num_records and the range check returns the zero padding by itself.  For rows above it the
+// scalar offset is replaced by a large one: they are the tile's first passes, those with more than `thr`
+// passes left.
+//
+// The cursor lives in SGPRs and advances on the SALU.  It is written as inline asm with "s" operands
+// because hipcc otherwise moves such wave-uniform add/select chains to the VALU under SGPR pressure
+// (v_add + v_readfirstlane per step -- each a VALU slot in the MFMA stream).
+struct StageSeq {      // wave-uniform cursor: the next pass
+    int j;             // pass index inside the tile row
+    int off;           // issue cursor: byte offset in the image of (tile row, column PPP*j - pad_l), may be negative;
+                       // commit cursor: LDS byte address of slot (tile row, PPP*j) in the destination buffer
+    int left;          // passes left in this tile
+    int thr;           // issue cursor: the passes done while left > thr lie in rows above the image
 };
 
+// One pass = four small statements, so that the group code can deal them out over different gaps of the
+// MFMA stream (about 4 SALU instructions per gap are free, 20 in one gap are not).
+// (1) EXEC mask of the cursor's pass, first half: row-start / row-end masks
+__device__ __forceinline__ void stage_mask_a(const StageSeq& q, const StageGeo& G, unsigned long long& m, unsigned long long& t) {
+    asm volatile("s_cmp_eq_u32 %2, 0\n\t"
+                 "s_cselect_b64 %0, %4, -1\n\t"
+                 "s_cmp_eq_u32 %2, %3\n\t"
+                 "s_cselect_b64 %1, %5, -1"
+                 : "=&s"(m), "=&s"(t) : "s"(q.j), "s"(G.JP1), "s"(G.m_first), "s"(G.m_last) : "scc");
+}
+// (2) second half: combine, nothing once the tile is complete; and the scalar offset (rows above the image)
+__device__ __forceinline__ void stage_mask_b(const StageSeq& q, unsigned long long& m, unsigned long long t, int& so) {
+    asm volatile("s_and_b64 %0, %0, %2\n\t"
+                 "s_cmp_gt_i32 %3, 0\n\t"
+                 "s_cselect_b64 %0, %0, 0\n\t"
+                 "s_cmp_gt_i32 %3, %4\n\t"
+                 "s_cselect_b32 %1, 0x7ff00000, %5"
+                 : "+s"(m), "=&s"(so) : "s"(t), "s"(q.left), "s"(q.thr), "s"(q.off) : "scc");
+}
+// (3) the load: 16 bytes per active lane, no VALU
+__device__ __forceinline__ f32x4 stage_fire(unsigned long long m, int so, __amdgpu_buffer_rsrc_t rsrc, int voff_lane) {
+    f32x4 v;
+    asm volatile("s_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen\n\ts_mov_b64 exec, -1"
+                 : "=&v"(v) : "v"(voff_lane), "s"(rsrc), "s"(so), "s"(m) : "memory");
+    return v;
+}
+// (4) advance a cursor by one pass
+template <int STEP>
+__device__ __forceinline__ void stage_next(StageSeq& q, int JP1, int rowfix) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %0, %4\n\t"          // last pass of the row?
+                 "s_cselect_b32 %3, %5, 0\n\t"
+                 "s_cselect_b32 %0, -1, %0\n\t"
+                 "s_add_i32 %1, %1, %3\n\t"
+                 "s_add_i32 %1, %1, %6\n\t"
+                 "s_add_i32 %0, %0, 1\n\t"
+                 "s_sub_i32 %2, %2, 1"
+                 : "+s"(q.j), "+s"(q.off), "+s"(q.left), "=&s"(tmp) : "s"(JP1), "s"(rowfix), "n"(STEP) : "scc");
+}
+// the LDS write of a pass (mask from its issue): wait until at most `pend` younger VMEM operations are
+// outstanding, one VALU (LDS address)
+#define SRX_COMMIT_ASM(N)                                                                                    \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_add_u32 %0, %3, %4\n\ts_mov_b64 exec, %2\n\tds_write_b128 %0, %1\n\ts_mov_b64 exec, -1" \
+                 : "=&v"(addr) : "v"(v), "s"(m), "s"(q.off), "v"(wl_lane) : "memory")
+__device__ __forceinline__ void stage_commit(int pend, const StageSeq& q, unsigned long long m, int wl_lane, const f32x4 v) {
+    int addr;
+    // (pend is a constant after unrolling: the chain folds to one statement)
+    if (pend >= 5) SRX_COMMIT_ASM(5);
+    else if (pend == 4) SRX_COMMIT_ASM(4);
+    else if (pend == 3) SRX_COMMIT_ASM(3);
+    else if (pend == 2) SRX_COMMIT_ASM(2);
+    else if (pend == 1) SRX_COMMIT_ASM(1);
+    else SRX_COMMIT_ASM(0);
+}
+// a whole pass at once (prologue / drain loops)
 template <int CINP>
-__device__ __forceinline__ void stage_begin(StageCtx<CINP>& sc, const float* xn, int H, int W, int Cin, int h_in0,
-                                            int w_in0, int RS, float inv_rs, int n_need, int sp, int c4, bool active) {
-    constexpr int PS = Lds<CINP>::PS;
+__device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
+                                               int voff_lane, int wl_lane) {
     constexpr int PPP = 256 / (CINP / 4);
-    sc.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, H * W * Cin * 4, 0x00020000);
-    sc.H = H; sc.W = W; sc.RS = RS; sc.n_need = n_need; sc.h_in0 = h_in0; sc.w_in0 = w_in0;
-    sc.step_bytes = PPP * Cin * 4;
-    sc.wrap_bytes = (W - RS) * Cin * 4;
-    sc.pass = 0;
-    sc.n_pass = active ? (n_need + PPP - 1) / PPP : 0;
-    sc.s = sp;
-    sc.r = fdiv_small(sp, inv_rs, RS);
-    sc.c = sp - sc.r * RS;
-    sc.voff = (((h_in0 + sc.r) * W + w_in0 + sc.c) * Cin + 4 * c4) * 4;
-    sc.loff = sp * PS + 4 * c4;
-    sc.active = active;
-    sc.ch_ok = 4 * c4 < Cin;
+    unsigned long long m, t;
+    int so;
+    stage_mask_a(qi, G, m, t);
+    stage_mask_b(qi, m, t, so);
+    const f32x4 v = stage_fire(m, so, rsrc, voff_lane);
+    stage_next<PPP * CINP * 4>(qi, G.JP1, G.rowfix_g);
+    stage_commit(0, qc, m, wl_lane, v);
+    stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
 }
 
-// issue the load of the cursor's slot
-template <int CINP>
-__device__ __forceinline__ f32x4 stage_issue(const StageCtx<CINP>& sc) {
-    const int ih = sc.h_in0 + sc.r, iw = sc.w_in0 + sc.c;
-    const bool ok = ((unsigned)ih < (unsigned)sc.H) & ((unsigned)iw < (unsigned)sc.W) & (sc.s < sc.n_need) & sc.active & sc.ch_ok;
-    const int off = ok ? sc.voff : 0x7fffffff;   // beyond num_records -> the load returns 0
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sc.rsrc, off, 0, 0));
-}
-
-// write a previously loaded slot (the one `back` passes behind the cursor) to the LDS buffer, then nothing else
-template <int CINP>
-__device__ __forceinline__ void stage_commit(const StageCtx<CINP>& sc, float* lnxt, int back, const f32x4 v) {
-    constexpr int PS = Lds<CINP>::PS;
-    constexpr int PPP = 256 / (CINP / 4);
-    const int s = sc.s - back * PPP;
-    if (sc.active && s < sc.n_need) *reinterpret_cast<f32x4*>(lnxt + sc.loff - back * PPP * PS) = v;
-}
-
-template <int CINP>
-__device__ __forceinline__ void stage_advance(StageCtx<CINP>& sc) {
-    // one wrap at most: the kernel enables shadow staging only when RS >= PPP
-    constexpr int PS = Lds<CINP>::PS;
-    constexpr int PPP = 256 / (CINP / 4);
-    sc.pass += 1;
-    sc.s += PPP; sc.loff += PPP * PS;
-    const int c1 = sc.c + PPP;
-    const bool wrap = c1 >= sc.RS;
-    sc.c = wrap ? c1 - sc.RS : c1;
-    sc.r += wrap ? 1 : 0;
-    sc.voff += sc.step_bytes + (wrap ? sc.wrap_bytes : 0);
-}
-
-// single MFMA statements for the pipelined kernel: weights from AGPRs; "memory" keeps the staging
-// loads / LDS accesses that are threaded between them in place
-#ifdef SRX_EXP_NOMEM
-#define SRX_MEMCLOB
-#else
-#define SRX_MEMCLOB : "memory"
-#endif
-__device__ __forceinline__ void mfma1_a(f32x4& c, float w, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(b) SRX_MEMCLOB);
-}
-__device__ __forceinline__ void mfma1_a_guard(f32x4& c, float w, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(b) : "memory");
-}
 // zero-cost ordering fence: code that uses x afterwards cannot be scheduled above this point, code that
 // produced x cannot sink below it (volatile asm statements keep their relative order)
 #define SRX_PIN(x) asm volatile("" : "+v"(x))
 
-template <int KH, int KW, int CINP, int G, bool AUX>
-__device__ __forceinline__ void conv_group_pipe(const float* lds, float* lnxt, const float (&wr)[KH * KW * (CINP / 4)],
-                                                const f32x4 bias4, const ConvArgs& a, StageCtx<CINP>& sc, int n, int h,
-                                                int ow0, int th, int tw, float inv_tw, int m_first, int m_step,
-                                                int n_active, int li, int kq, int cout0, int sp, int c4,
-                                                unsigned long long (&tt)[4]) {
+template <int MAXG, int AUX>
+struct PipePend {      // a finished group waiting for its epilogue
+    f32x4 acc[MAXG];
+    f32x4 aux[AUX ? MAXG : 1];
+    float* ybase;      // wave-uniform: y of (image, first row of the unit)
+    int m_first, gs, npx;
+};
+struct PipeEpi {
+    int lo, lo2;       // wave-uniform clamps
+    int cout4;         // Cout * 4
+};
+// AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add
+template <int AUX>
+__device__ __forceinline__ PipeEpi pipe_epi_setup(const ConvArgs& a) {
+    PipeEpi e;
+    e.lo = (a.act == ACT_RELU) ? 0 : (int)0x80000000;
+    e.lo2 = (AUX == 2 && a.post_relu) ? 0 : (int)0x80000000;
+    e.cout4 = a.Cout * 4;
+    return e;
+}
+__device__ __forceinline__ f32x4 clamp_lo4(f32x4 v, int lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float f = v[e];                 // (bit_cast straight on a vector element miscompiles)
+        const int b = __float_as_int(f);
+        v[e] = __int_as_float(b > lo ? b : lo);
+    }
+    return v;
+}
+// Buffer resource of sub-tile m of a unit: base = its first pixel, num_records = the bytes of its pixels that
+// exist (npx - 16m of them, 16 at most matter) -> the range check drops the tail of a short last sub-tile.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t subtile_rsrc(const float* unit_base, int m, int npx, bool live, int cout4) {
+    const int rem = npx - 16 * m;
+    const int nrec = (live && rem > 0) ? rem * cout4 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(unit_base) + (size_t)(4 * m) * cout4, 0, nrec, 0x00020000);
+}
+// Epilogue of ONE parked sub-tile.  The host sends only these forms to the pipelined kernel:
+//   no aux:  y = max_int(acc, lo)                    lo = 0 (ReLU) or INT_MIN (no activation)
+//   mask:    y = (mask > 0) ? acc : 0                ReluGrad on the saved activation (dgrad)
+//   skip:    y = max_int(max_int(acc, lo) + skip, lo2)      residual add, optional ReLU after it
+template <int MAXG, int AUX, int NPART>
+__device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd, int i, const PipeEpi& ep, int vst) {
+    f32x4 v = pd.acc[i];
+    if (AUX == 1) {
+        const f32x4 m = pd.aux[AUX ? i : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mf = m[e], f = v[e];
+            v[e] = (__float_as_int(mf) > 0) ? f : 0.0f;
+        }
+    } else if (AUX == 2) {
+        v = clamp_lo4(clamp_lo4(v, ep.lo) + pd.aux[AUX ? i : 0], ep.lo2);
+    } else {
+        v = clamp_lo4(v, ep.lo);
+    }
+    const __amdgpu_buffer_rsrc_t r = subtile_rsrc(pd.ybase, pd.m_first + i * NPART, pd.npx, i < pd.gs, ep.cout4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, vst, 0, 0);
+}
+
+// One k-step (4 input channels of one tap) for G accumulators: G MFMAs, weight from an AGPR.
+#define SRX_MFMA_AV(ACC, B) "v_mfma_f32_16x16x4_f32 %" #ACC ", %4, %" #B ", %" #ACC "\n\t"
+__device__ __forceinline__ void mfma_sub_a(f32x4 (&c)[4], float w, float b0, float b1, float b2, float b3) {
+    asm volatile(SRX_MFMA_AV(0, 5) SRX_MFMA_AV(1, 6) SRX_MFMA_AV(2, 7) SRX_MFMA_AV(3, 8)
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "a"(w), "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");
+}
+#define SRX_MFMA_AV3(ACC, B) "v_mfma_f32_16x16x4_f32 %" #ACC ", %3, %" #B ", %" #ACC "\n\t"
+__device__ __forceinline__ void mfma_sub_a(f32x4 (&c)[3], float w, float b0, float b1, float b2, float) {
+    asm volatile(SRX_MFMA_AV3(0, 4) SRX_MFMA_AV3(1, 5) SRX_MFMA_AV3(2, 6)
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "a"(w), "v"(b0), "v"(b1), "v"(b2) : "memory");
+}
+// the group's very first k-step: the accumulators are DEFINED here, C operand = bias (no VALU initialisation)
+#define SRX_MFMA_AVC(ACC, B) "v_mfma_f32_16x16x4_f32 %" #ACC ", %4, %" #B ", %9\n\t"
+__device__ __forceinline__ void mfma_sub_a_first(f32x4 (&c)[4], f32x4 bias4, float w, float b0, float b1, float b2, float b3) {
+    asm volatile(SRX_MFMA_AVC(0, 5) SRX_MFMA_AVC(1, 6) SRX_MFMA_AVC(2, 7) SRX_MFMA_AVC(3, 8)
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "a"(w), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(bias4) : "memory");
+}
+#define SRX_MFMA_AVC3(ACC, B) "v_mfma_f32_16x16x4_f32 %" #ACC ", %3, %" #B ", %7\n\t"
+__device__ __forceinline__ void mfma_sub_a_first(f32x4 (&c)[3], f32x4 bias4, float w, float b0, float b1, float b2, float) {
+    asm volatile(SRX_MFMA_AVC3(0, 4) SRX_MFMA_AVC3(1, 5) SRX_MFMA_AVC3(2, 6)
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2])
+                 : "a"(w), "v"(b0), "v"(b1), "v"(b2), "v"(bias4) : "memory");
+}
+
+struct PipeUnit {      // wave-uniform description of the running unit
+    int npx;
+    float* ybase;
+    const float* auxbase;
+};
+
+// One group of G (<= MAXG) sub-tiles m_first, m_first+NPART, ...  On entry `cur` holds the LDS fragments of
+// the group's first block and la[] its sub-tiles' LDS byte addresses; on exit the group is parked in `pd`
+// and la / cur describe the unit's next group (tcur is the per-lane cursor into the address table).
+//
+// Instruction placement: a block (one tap x 16 input channels) is four k-step statements of G MFMAs; the
+// other work is cut into pieces and dealt out over the gaps between them:
+//                  gap 0..2 of every block: the LDS reads of the next block;
+//                  blocks 0..NST-1, gap 0: one staging pass (scalar cursor + masked bounds-checked load);
+//                  blocks NBLK/2.., gap 1: the LDS write of that pass;
+//                  blocks E0.., gap 1: the previous group's epilogue, one sub-tile per block;
+//                  block A0, gap 3: the next group's LDS addresses (table reads).
+// No branches in here: every taken branch stalls the stream for an instruction refetch.
+template <int KH, int KW, int CINP, int G, int MAXG, int AUX, int NPART>
+__device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&wr)[KH * KW * (CINP / 4)],
+                                                const f32x4 bias4, int row_stride_b, StageSeq& qi, StageSeq& qc,
+                                                const StageGeo& SG, __amdgpu_buffer_rsrc_t xrs, int voff_lane, int wl_lane,
+                                                int (&la)[MAXG], f32x4 (&cur)[MAXG], int& tcur,
+                                                PipePend<MAXG, AUX>& pd, const PipeUnit& un, int m_first, int gs,
+                                                const PipeEpi& ep, int vst, unsigned long long (&tt)[4]) {
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = CINP / 16;
     constexpr int NBLK = KH * KW * NG;
-    const unsigned long long ts_p = SRX_STAMP();
-#ifdef SRX_EXP_NOST
-    constexpr int NST = 0;
-#else
     constexpr int NST = (NBLK / 2 < 6) ? NBLK / 2 : 6;   // staging passes threaded through this group
-#endif
-    const int npx = th * tw;
-    const int cb = cout0 + 4 * kq;
-    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
-    const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;
-    int laddr[G];
-    unsigned off[G];
-    bool valid[G];
-    f32x4 acc[G];
-    // pixel (row, col) of this lane in the group's first sub-tile by one division; the following sub-tiles
-    // (stride 16*m_step pixels) by integer add-and-wrap when a single wrap suffices
-    const int t0 = 16 * m_first + li;
-    int orow = fdiv_small(t0 < npx ? t0 : 0, inv_tw, tw);
-    int ocol = (t0 < npx ? t0 : 0) - orow * tw;
-    const int dstep = 16 * m_step;
-    const bool inc_ok = dstep <= tw;
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        const int t = t0 + i * dstep;
-        const bool live = (t < npx) & (i < n_active);
-        valid[i] = live & (cb < a.Cout);
-        if (i > 0) {
-            if (inc_ok) {
-                const int c1 = ocol + dstep;
-                const bool wrap = c1 >= tw;
-                ocol = wrap ? c1 - tw : c1;
-                orow += wrap ? 1 : 0;
-            } else {
-                const int tt = t < npx ? t : 0;
-                orow = fdiv_small(tt, inv_tw, tw);
-                ocol = tt - orow * tw;
-            }
-        }
-        const int prow = live ? orow : 0, pcol = live ? ocol : 0;
-        laddr[i] = (prow * a.RS + pcol) * PS + 4 * kq;
-        off[i] = valid[i] ? (unsigned)(((h + prow) * a.OW + ow0 + pcol) * a.Cout + cb) : 0u;
-        acc[i] = bias4;
-    }
-    f32x4 aux[G];
-    conv_prefetch_aux<G, AUX>(aux, off, a, img_base, vec);
-    const int row_stride = a.RS * PS;
-
-    f32x4 stg[NST > 0 ? NST : 1];
-    f32x4 cur[G], nxt[G];
-    const int pass_base = sc.pass;
+    constexpr int E0 = NST;                               // first epilogue block
+    constexpr int A0 = NST + MAXG;                        // address block
+    constexpr int TSTEP = 16 * PS * 4 * NPART;            // table bytes from one sub-tile of the wave to the next
+    constexpr int PPP = 256 / (CINP / 4);
+    static_assert(NBLK >= NST + MAXG + 2, "group too short for the dealt-out schedule");
     const unsigned long long ts_m = SRX_STAMP();
-    tt[0] += ts_m - ts_p;
+    f32x4 acc[G];
+    f32x4 aux[AUX ? G : 1];
+    if (AUX) {
 #pragma unroll
-    for (int i = 0; i < G; ++i) cur[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i]);
-    // Per block (one tap x 16 input channels) ONE asm statement of 4G MFMAs: every extra instruction in
-    // this stream costs MFMA issue time (about 3 cycles each, measured), and separate statements make the
-    // compiler re-emit an s_waitcnt per statement.  Between blocks: the LDS reads of the next block and,
-    // in blocks 0..NST-1 / NBLK/2..NBLK/2+NST-1, one lean staging slot (issue / LDS write) for the next tile.
+        for (int i = 0; i < G; ++i) {
+            const __amdgpu_buffer_rsrc_t r = subtile_rsrc(un.auxbase, m_first + i * NPART, un.npx, i < gs, ep.cout4);
+            aux[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vst, 0, 0));
+        }
+    }
+    int lan[MAXG];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) lan[i] = 0;
+    f32x4 stg[NST];
+    unsigned long long mk[NST], mt;
+    int so;
+    f32x4 nxt[MAXG];
+    f32x4 cg[MAXG];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) cg[i] = cur[i];
 #pragma unroll
     for (int t = 0; t < NBLK; ++t) {
-        if (t + 1 < NBLK) {
-            const int t1 = t + 1;
-            const int kh1 = (t1 / NG) / KW, kw1 = (t1 / NG) % KW, g1 = t1 % NG;
+        const int tap = t / NG, gg = t % NG;
+        const int wb = tap * (CINP / 4) + 4 * gg;
+        const bool last = (t + 1 == NBLK);
+        const int t1 = t + 1;
+        const int kh1 = (t1 / NG) / KW, kw1 = (t1 / NG) % KW, g1 = t1 % NG;
+        // LDS fragment i of the next block -- or, in the last block, of the next group's first block
+        auto frag = [&](int i) {
+            nxt[i] = last ? *reinterpret_cast<const f32x4*>(ldsb + lan[i])
+                          : *reinterpret_cast<const f32x4*>(ldsb + la[i] + kh1 * row_stride_b + (kw1 * PS + 16 * g1) * 4);
+        };
+        const int nfr = last ? MAXG : G;     // fragments to fetch during this block
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                nxt[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i] + kh1 * row_stride + kw1 * PS + 16 * g1);
-        }
-        // (wave-uniform tests: passes beyond the tile's last one cost nothing)
-        if (NST > 0 && t < NST && pass_base + t < sc.n_pass) {
-            stg[t % (NST > 0 ? NST : 1)] = stage_issue<CINP>(sc);
-            stage_advance<CINP>(sc);
-        }
-        if (NST > 0 && t >= NBLK / 2 && t < NBLK / 2 + NST) {
-            const int j = t - NBLK / 2;
-            if (pass_base + j < sc.n_pass)
-                stage_commit<CINP>(sc, lnxt, sc.pass - (pass_base + j), stg[j % (NST > 0 ? NST : 1)]);
-        }
-        const int tap = t / NG, g = t % NG;
-        const int wb = tap * (CINP / 4) + 4 * g;
-        if (t == 0)
-            mfma_block_a<true>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
-        else
-            mfma_block_a<false>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+        for (int ks = 0; ks < 4; ++ks) {
+            if (t == 0 && ks == 0)
+                mfma_sub_a_first(acc, bias4, wr[wb + ks], cg[0][ks], cg[1][ks], cg[2][ks], cg[G - 1][ks]);
+            else
+                mfma_sub_a(acc, wr[wb + ks], cg[0][ks], cg[1][ks], cg[2][ks], cg[G - 1][ks]);
+            // ---- gap ks
+            if (ks == 0) {
+                frag(0);
+                if (t < NST) stage_mask_a(qi, SG, mk[t], mt);
+            } else if (ks == 1) {
+                frag(1);
+                if (t < NST) stage_mask_b(qi, mk[t], mt, so);
+                if (t >= NBLK / 2 && t < NBLK / 2 + NST)
+                    stage_commit(NST - 1 - (t - NBLK / 2), qc, mk[t - NBLK / 2], wl_lane, stg[t - NBLK / 2]);
+                if (t >= E0 && t < E0 + MAXG) {
+                    SRX_PIN(pd.acc[t - E0]);
+                    pipe_epilogue_one<MAXG, AUX, NPART>(pd, t - E0, ep, vst);
+                }
+            } else if (ks == 2) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+                for (int i = 2; i < nfr; ++i) frag(i);
+                if (t < NST) stg[t] = stage_fire(mk[t], so, xrs, voff_lane);
+                if (t >= NBLK / 2 && t < NBLK / 2 + NST) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
+            } else {
+                if (t < NST) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);
+                if (t == A0) {
+                    // the next group's LDS addresses: its sub-tiles are the next MAXG table entries of this lane
+                    tcur += gs * TSTEP;
+#pragma unroll
+                    for (int i = 0; i < MAXG; ++i) lan[i] = *reinterpret_cast<const int*>(ldsb + tcur + i * TSTEP);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < nfr; ++i) cg[i] = nxt[i];
     }
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    const unsigned long long ts_e = SRX_STAMP();
-    tt[1] += ts_e - ts_m;
-    conv_epilogue<G, AUX>(acc, aux, valid, off, a, img_base, cb, vec);
-    tt[2] += SRX_STAMP() - ts_e;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) { cur[i] = cg[i]; la[i] = lan[i]; }
+    // park the group: software must cover the MFMA result latency before anything reads the accumulators
+    // (here only the compiler's register moves; the arithmetic happens inside the next group)
+    if constexpr (G == 4)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        pd.acc[i] = (i < G) ? acc[i < G ? i : 0] : bias4;
+        if (AUX) pd.aux[i] = (i < G) ? aux[i < G ? i : 0] : bias4;
+    }
+    pd.ybase = un.ybase; pd.m_first = m_first; pd.gs = gs; pd.npx = un.npx;
+    tt[1] += SRX_STAMP() - ts_m;
 }
 
-template <int KH, int KW, int CINP, int NCH, bool WT, bool AUX>
+template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
 __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TAPS = KH * KW;
     constexpr int KSPT = CINP / 4;
     constexpr int NPART = 4 / NCH;
     constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int MAXG = 4;
+    constexpr int TSTEP = 16 * PS * 4 * NPART;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int chunk = wave % NCH, part = wave / NCH;
     const int cout0 = chunk * 16;
+    const int cb = cout0 + 4 * kq;
     const int c4 = tid % TPP, sp = tid / TPP;
+    char* ldsb = reinterpret_cast<char*>(lds);
 
 #ifdef SRX_TRACE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
@@ -871,7 +1013,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     {
         load_stationary_weights<TAPS, CINP, WT>(wr, a, cout0, li, kq);
         // all loads are in flight; now move the weights into the accumulation-register file for good: they
-        // are defined as "a" values here and only ever consumed by "a" operands of the MFMA blocks.
+        // are defined as "a" values here and only ever consumed by "a" operands of the MFMA statements.
         // (One asm per weight right after its own load would serialise 144 global-load round trips.)
 #pragma unroll
         for (int i = 0; i < TAPS * KSPT; ++i) {
@@ -883,90 +1025,163 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     if (a.bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (cout0 + 4 * kq + e < a.Cout) bias4[e] = a.bias[cout0 + 4 * kq + e];
+            if (cb + e < a.Cout) bias4[e] = a.bias[cb + e];
     }
 
     const long G_ = gridDim.x;
     const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
     const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
     if (u0 >= u1) return;
-    const int buf_floats = a.buf_floats;
-    const bool vec_in = (a.Cin & 3) == 0;
+    // The host sends only shapes this scheme covers: exact-fit channels (Cin == CINP), full-width tiles
+    // (NTX == 1, tw == OW), Cout a multiple of 4, images below 2^31 bytes, epilogue forms as listed above.
+    const int buf_bytes = a.buf_floats * 4;
+    const int rows_full = a.TH + KH - 1;
+    const int row_stride_b = a.RS * PS * 4;
+
+    // ---- one-time LDS set-up in BOTH buffers: the pad columns (zero for good: no pass ever writes them) and
+    // the sub-tile address table in the slots' pad bytes: entry (m, L) = LDS byte address (in that buffer) of
+    // pixel 16m + (L & 15) of a tile, channel 4 * (L >> 4); it sits in pad word (L & 3) of slot 16m + (L >> 2).
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < (rows_full + 1) * a.pad_l * TPP; i += 256) {
+            const int q = i / TPP, ch = i % TPP;
+            const int r = q / a.pad_l, c = q % a.pad_l;
+            const int off = ((r * a.RS + c) * PS + 4 * ch) * 4;
+            if ((r * a.RS + c) * PS * 4 < buf_bytes) {
+                *reinterpret_cast<f32x4*>(ldsb + off) = z;
+                *reinterpret_cast<f32x4*>(ldsb + buf_bytes + off) = z;
+            }
+        }
+        const int n_sub_max = (a.TH * a.OW + 15) >> 4;
+        for (int i = tid; i < n_sub_max * 64; i += 256) {
+            const int m = i >> 6, L = i & 63;
+            const int t = 16 * m + (L & 15);
+            int addr = 0;
+            if (t < a.TH * a.OW) {
+                const int orow = t / a.OW, ocol = t - orow * a.OW;
+                addr = ((orow * a.RS + ocol) * PS + 4 * (L >> 4)) * 4;
+            }
+            const int where = ((16 * m + (L >> 2)) * PS + CINP + (L & 3)) * 4;
+            *reinterpret_cast<int*>(ldsb + where) = addr;
+            *reinterpret_cast<int*>(ldsb + buf_bytes + where) = buf_bytes + addr;
+        }
+    }
+    // ---- per-lane constants
+    const int voff_lane = tid * 16;                         // image bytes of (slot sp, chunk c4) inside a pass
+    const int wl_lane = (sp * PS + 4 * c4) * 4;             // the same inside LDS
+    const int vst = (cb < a.Cout) ? (li * a.Cout + cb) * 4 : kOobOffset;   // output bytes inside a sub-tile
+    const int tlane = (((lane >> 2) + 16 * part) * PS + CINP + (lane & 3)) * 4;   // this lane's table entry of sub-tile `part`
+    StageGeo SG;
+    const int JP = (a.RS + PPP - 1) / PPP;
+    SG.JP1 = __builtin_amdgcn_readfirstlane(JP - 1);
+    SG.rowfix_g = __builtin_amdgcn_readfirstlane((a.W - JP * PPP) * CINP * 4);
+    SG.rowfix_l = __builtin_amdgcn_readfirstlane((a.RS - JP * PPP) * PS * 4);
+    SG.m_first = uniform64(__ballot(sp >= a.pad_l));
+    SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
+    const PipeEpi ep = pipe_epi_setup<AUX>(a);
+    const float* auxp = a.mask ? a.mask : a.skip;
 
     // tile descriptor of unit u (wave-uniform)
-    auto tile_of = [&](int u, int& n, int& h, int& th, int& ow0, int& tw) {
+    auto tile_of = [&](int u, int& n, int& h, int& th) {
         h = u % a.OH;
-        const int t = u / a.OH;
-        const int tx = t % a.NTX;
-        n = t / a.NTX;
+        n = u / a.OH;
         th = a.TH;
         if (a.OH - h < th) th = a.OH - h;
         if (u1 - u < th) th = u1 - u;
-        ow0 = tx * a.TW;
-        tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
+    };
+    // cursors of a tile's staging: qi walks the image (issue), qc the LDS buffer (commit)
+    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int buf, bool active) {
+        // (readfirstlane: once per tile, so that the cursors provably start out in SGPRs)
+        const int left = __builtin_amdgcn_readfirstlane(active ? (th + KH - 1) * JP : 0);
+        qi.j = 0; qc.j = 0;
+        qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+        qc.off = __builtin_amdgcn_readfirstlane(buf * buf_bytes);
+        qi.left = left; qc.left = left;
+        const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;      // passes in rows above the image
+        qi.thr = __builtin_amdgcn_readfirstlane(left - above);
+        qc.thr = 0;
     };
 
-    unsigned long long tt[4] = {0, 0, 0, 0};   // trace: group prologue, MFMA+shadow section, epilogue, drain+barrier
-    int n, h, th, ow0, tw;
-    tile_of(u0, n, h, th, ow0, tw);
+    unsigned long long tt[4] = {0, 0, 0, 0};   // trace: unit prologue, group sections, -, drain+barrier
+    int n, h, th;
+    tile_of(u0, n, h, th);
     const unsigned long long t_begin = SRX_STAMP();
-    stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs,
-                     (th + KH - 1) * a.RS + (KW - 1), tid);
+    __syncthreads();     // (set-up writes above vs. the first tile's writes below touch different bytes; this orders them with the reads)
+    {
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h, th, 0, true);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
+        while (qi.left > 0) stage_pass_now<CINP>(qi, qc, SG, xrs, voff_lane, wl_lane);
+    }
     lds_barrier();
     const unsigned long long t_first = SRX_STAMP();
 
-    int cur = 0;
+    PipePend<MAXG, AUX> pd;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) pd.acc[i] = bias4;
+    if (AUX) {
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) pd.aux[i] = bias4;
+    }
+    pd.ybase = a.y; pd.m_first = 0; pd.gs = 0; pd.npx = 0;
+
+    int cur_buf = 0;
     int u = u0;
     while (u < u1) {
-        tile_of(u, n, h, th, ow0, tw);
-        const int un = u + th;
-        const bool has_next = un < u1;
-        int n2 = n, h2 = h, th2 = th, ow02 = ow0, tw2 = tw;
-        if (has_next) tile_of(un, n2, h2, th2, ow02, tw2);
-        StageCtx<CINP> sc;
-        stage_begin<CINP>(sc, a.x + (size_t)n2 * a.H * a.W * a.Cin, a.H, a.W, a.Cin, h2 - a.pad_t, ow02 - a.pad_l, a.RS,
-                          a.inv_rs, (th2 + KH - 1) * a.RS + (KW - 1), sp, c4, has_next && vec_in && a.RS >= PPP && !(a.dbg & 4));
-        const float* lcur = lds + cur * buf_floats;
-        float* lnxt = lds + (cur ^ 1) * buf_floats;
+        const unsigned long long ts_u = SRX_STAMP();
+        tile_of(u, n, h, th);
+        const int un_ = u + th;
+        const bool has_next = un_ < u1;
+        int n2 = n, h2 = h, th2 = th;
+        if (has_next) tile_of(un_, n2, h2, th2);
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h2, th2, cur_buf ^ 1, has_next);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + ((size_t)n2 * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
 
-        const int n_sub = (th * tw + 15) >> 4;
+        PipeUnit un;
+        un.npx = th * a.OW;
+        const size_t unit_off = ((size_t)n * a.OH + h) * a.OW * a.Cout;
+        un.ybase = a.y + unit_off;
+        un.auxbase = AUX ? auxp + unit_off : a.x;
+
+        const int n_sub = (un.npx + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;
-        const float inv_tw = 1.0f / (float)tw;
         if (cnt > 0) {
-            constexpr int MAXG = AUX ? 3 : 4;
             const int ng = (cnt + MAXG - 1) / MAXG;
             const int base = cnt / ng, rem = cnt % ng;
+            int tcur = cur_buf * buf_bytes + tlane;
+            int la[MAXG];
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) la[i] = *reinterpret_cast<const int*>(ldsb + tcur + i * TSTEP);
+            f32x4 cur[MAXG];
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) cur[i] = *reinterpret_cast<const f32x4*>(ldsb + la[i]);
+            tt[0] += SRX_STAMP() - ts_u;
             int idx = 0;
             for (int gi = 0; gi < ng; ++gi) {
                 const int gs = base + (gi < rem ? 1 : 0);
                 const int m_first = part + idx * NPART;
                 if (gs == MAXG)
-                    conv_group_pipe<KH, KW, CINP, MAXG, AUX>(lcur, lnxt, wr, bias4, a, sc, n, h, ow0, th, tw, inv_tw, m_first,
-                                                             NPART, gs, li, kq, cout0, sp, c4, tt);
+                    conv_group_pipe<KH, KW, CINP, MAXG, MAXG, AUX, NPART>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
+                                                                          wl_lane, la, cur, tcur, pd, un, m_first, gs, ep, vst, tt);
                 else
-                    conv_group_pipe<KH, KW, CINP, MAXG - 1, AUX>(lcur, lnxt, wr, bias4, a, sc, n, h, ow0, th, tw, inv_tw,
-                                                                 m_first, NPART, gs, li, kq, cout0, sp, c4, tt);
+                    conv_group_pipe<KH, KW, CINP, MAXG - 1, MAXG, AUX, NPART>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
+                                                                              wl_lane, la, cur, tcur, pd, un, m_first, gs, ep, vst, tt);
                 idx += gs;
             }
         }
-        // drain: whatever part of the next tile the groups did not cover (short tiles, ragged channels)
+        // drain: whatever part of the next tile the groups did not cover
         const unsigned long long ts_d = SRX_STAMP();
-        if (has_next) {
-            if (vec_in && a.RS >= PPP && !(a.dbg & 4)) {
-                while (sc.pass < sc.n_pass) {
-                    const f32x4 v = stage_issue<CINP>(sc);
-                    stage_advance<CINP>(sc);
-                    stage_commit<CINP>(sc, lnxt, 1, v);
-                }
-            } else {
-                stage_tile<CINP>(lnxt, a.x, n2, a.H, a.W, a.Cin, h2 - a.pad_t, ow02 - a.pad_l, a.RS, a.inv_rs, sc.n_need, tid);
-            }
-        }
+        while (qi.left > 0) stage_pass_now<CINP>(qi, qc, SG, xrs, voff_lane, wl_lane);
         lds_barrier();
         tt[3] += SRX_STAMP() - ts_d;
-        cur ^= 1;
-        u = un;
+        cur_buf ^= 1;
+        u = un_;
     }
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) pipe_epilogue_one<MAXG, AUX, NPART>(pd, i, ep, vst);
 #ifdef SRX_TRACE
     if (a.trace && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;

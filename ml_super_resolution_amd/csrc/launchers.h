@@ -50,12 +50,21 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
         return true;                                                                                      \
     }
 // Pipelined one-wave-per-SIMD kernel (>= 16 input channels): one workgroup per CU, two LDS buffers.
-#define SRX_PIPE_CASE(KH, KW, CINP, NCH, WT)                                                              \
-    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt == WT) {                       \
-        if (a.skip || a.mask)                                                                             \
-            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, WT, true>, a, grid, lds, s);       \
+// (forward launches carry at most a residual operand, dgrad launches at most a ReluGrad mask)
+#define SRX_PIPE_CASE_FWD(KH, KW, CINP, NCH)                                                              \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && !k.wt) {                            \
+        if (a.skip)                                                                                       \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, false, 2>, a, grid, lds, s);       \
         else                                                                                              \
-            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, WT, false>, a, grid, lds, s);      \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, false, 0>, a, grid, lds, s);       \
+        return true;                                                                                      \
+    }
+#define SRX_PIPE_CASE_DGRAD(KH, KW, CINP, NCH)                                                            \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt) {                             \
+        if (a.mask)                                                                                       \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, true, 1>, a, grid, lds, s);        \
+        else                                                                                              \
+            *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, true, 0>, a, grid, lds, s);        \
         return true;                                                                                      \
     }
 #define SRX_WGRAD_CASE(KH, KW, CINP, NCH, MINW)                                                           \

@@ -2,12 +2,12 @@
 #include "launchers.h"
 namespace srx {
 bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
-    SRX_PIPE_CASE(3, 3, 64, 4, false)
-    SRX_PIPE_CASE(3, 3, 64, 4, true)
-    SRX_PIPE_CASE(3, 3, 64, 2, false)
-    SRX_PIPE_CASE(3, 3, 64, 2, true)
-    SRX_PIPE_CASE(3, 3, 64, 1, false)
-    SRX_PIPE_CASE(3, 3, 64, 1, true)
+    SRX_PIPE_CASE_FWD(3, 3, 64, 4)
+    SRX_PIPE_CASE_DGRAD(3, 3, 64, 4)
+    SRX_PIPE_CASE_FWD(3, 3, 64, 2)
+    SRX_PIPE_CASE_DGRAD(3, 3, 64, 2)
+    SRX_PIPE_CASE_FWD(3, 3, 64, 1)
+    SRX_PIPE_CASE_DGRAD(3, 3, 64, 1)
     return false;
 }
 }  // namespace srx

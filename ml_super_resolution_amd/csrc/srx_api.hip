@@ -132,10 +132,20 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     ConvKey k{p.KH, p.KW, p.cinp, p.nch, wt};
     hipError_t err = hipSuccess;
     ConvArgs a = a_in;
-    // Main path for >= 16 input channels: the pipelined one-wave-per-SIMD kernel, one workgroup per
-    // CU with two LDS tile buffers.  SRX_PIPE=0 selects the older two-workgroups-per-CU kernels (A/B).
-    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 0; }
-    if (g_use_pipe && p.cinp >= 16) {
+    // Main path for the 3x3 body layers: the pipelined one-wave-per-SIMD kernel, one workgroup per CU with
+    // two LDS tile buffers (measured 7 % faster than the two-workgroups-per-CU kernels at 256x41x41x64).
+    // SRX_PIPE=0 / srx_set_conv_path(0) selects the two-workgroup kernels for everything (A/B).
+    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
+    // Its lean staging cursor / sub-tile walk / buffer-store epilogue cover: exact-fit channels, full-width
+    // tiles, a row stride of at least one staging pass, sub-tile steps of at most one row, 16-byte output
+    // vectors and images below 2^31 bytes.  Every other shape stays on the two-workgroup kernels.
+    const int ppp = 256 / (p.cinp / 4), npart = 4 / p.nch;
+    // Epilogue forms it implements (integer-VALU only): none / ReLU, ReLU-gradient mask, residual add (+ ReLU).
+    const bool epi_ok = (a.act == ACT_NONE || a.act == ACT_RELU) && !(a.mask && a.skip) && !(wt && a.skip) && !(!wt && a.mask) &&
+                        (!a.mask || (a.mask_act == ACT_RELU && a.act == ACT_NONE && !a.post_relu));
+    const bool pipe_ok = epi_ok && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && 16 * npart <= a.OW && (a.Cout & 3) == 0 &&
+                         (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
+    if (g_use_pipe && p.cinp >= 16 && pipe_ok) {
         const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
         a.buf_floats = (int)(p.lds_bytes / 4);
         if (launch_pipe_k3c64(k, a, pgrid, 2 * p.lds_bytes, s, &err) ||
@@ -212,7 +222,7 @@ extern "C" {
 const char* srx_version(void) { return "srx 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 const char* srx_last_error(void) { return g_err; }
 int srx_set_conv_path(int pipelined) {
-    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 0; }
+    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
     const int old = g_use_pipe;
     g_use_pipe = pipelined ? 1 : 0;
     return old;
