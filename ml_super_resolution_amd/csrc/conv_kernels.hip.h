@@ -777,6 +777,31 @@ __device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const
     stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
 }
 
+// a whole tile with NB loads in flight (kernels that stage between their MFMA phases)
+template <int CINP, int NB>
+__device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
+                                                  int voff_lane, int wl_lane) {
+    constexpr int PPP = 256 / (CINP / 4);
+    while (qi.left > 0) {
+        f32x4 v[NB];
+        unsigned long long mk[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            unsigned long long t;
+            int so;
+            stage_mask_a(qi, G, mk[i], t);
+            stage_mask_b(qi, mk[i], t, so);
+            v[i] = stage_fire(mk[i], so, rsrc, voff_lane);
+            stage_next<PPP * CINP * 4>(qi, G.JP1, G.rowfix_g);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            stage_commit(NB - 1 - i, qc, mk[i], wl_lane, v[i]);
+            stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
+        }
+    }
+}
+
 // zero-cost ordering fence: code that uses x afterwards cannot be scheduled above this point, code that
 // produced x cannot sink below it (volatile asm statements keep their relative order)
 #define SRX_PIN(x) asm volatile("" : "+v"(x))
@@ -1455,6 +1480,256 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
             }
         }
         __builtin_amdgcn_s_setprio(2);
+        u += th;
+    }
+
+    // MFMA results are read by VALU / stores next
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // ---- write this workgroup's partial
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 64 * q + 4 * (4 * kq + r) + g;
+                const int tap = R / CINP, ci = R % CINP;
+                if (R < ROWS && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgrad, linear walk (full-width tiles).  Same data flow as wgrad_mfma_kernel -- accumulators
+// stationary, x from the LDS halo tile, dpre from global -- but the K loop walks the PADDED positions
+// p' = orow*RS + ocol of the tile, 4 per step, instead of the real pixels.  In that space the x operand
+// of (position, tap) is LDS slot p' + kh*RS + kw: per lane a constant plus step*const, i.e. ds_read
+// immediates inside an unrolled window of U steps and one v_add per fragment stream per window.  The
+// dpre operand of the fake positions (ocol >= OW) must be 0 and the real ones sit at pixel
+// p' - orow*(RS-OW): a scalar state machine (column of the step's first position) classifies the step's
+// four positions -- before the row end, fake, in the next row -- as lane masks, and one bounds-checked
+// buffer load per step takes its lane offset through two selects on them (next-row lanes start
+// RS-OW pixels earlier, fake lanes are sent out of range -> 0); the step part of the address is the
+// scalar offset.  VALU instructions per 36-MFMA step: 3 (two selects, bias-gradient add) + 9/U, against ~46 in
+// wgrad_mfma_kernel (cursor advances, end-of-tile selects, address adds).  See conv_pipe_kernel for why
+// that is what matters.
+// ---------------------------------------------------------------------------------------------
+struct DpreSeq {       // wave-uniform state of the dpre stream: the next step to load
+    int c0;            // column (0..RS-1) of the step's first position
+    int soff;          // byte offset of that position's real pixel from the unit's first pixel, channel 0
+};
+__device__ __forceinline__ void dpre_counts(const DpreSeq& q, int tw, int RS, int& nA, int& nAF) {
+    asm volatile("s_sub_i32 %0, %3, %2\n\ts_max_i32 %0, %0, 0\n\ts_min_i32 %0, %0, 4\n\t"
+                 "s_sub_i32 %1, %4, %2\n\ts_min_i32 %1, %1, 4"
+                 : "=&s"(nA), "=&s"(nAF) : "s"(q.c0), "s"(tw), "s"(RS) : "scc");
+}
+// lanes of the first n (0..4) 16-lane groups
+__device__ __forceinline__ unsigned long long low_groups_mask(int n) {
+    unsigned long long m;
+    int w;
+    asm volatile("s_lshl_b32 %1, %2, 4\n\ts_bfm_b64 %0, %1, 0\n\ts_cmp_eq_u32 %2, 4\n\ts_cselect_b64 %0, -1, %0"
+                 : "=&s"(m), "=&s"(w) : "s"(n) : "scc");
+    return m;
+}
+__device__ __forceinline__ void dpre_masks(unsigned long long mA, unsigned long long mAF, unsigned long long& mF,
+                                           unsigned long long& mB) {
+    asm volatile("s_andn2_b64 %0, %3, %2\n\ts_not_b64 %1, %3" : "=&s"(mF), "=&s"(mB) : "s"(mA), "s"(mAF) : "scc");
+}
+// The load itself is an ordinary (compiler-visible) buffer load: the compiler tracks its latency, and the
+// prefetch ring may live across loop back-edges.  Only the lane offset is patched, by two selects on the
+// scalar masks (2 VALU per step): next-row lanes start pad pixels earlier, fake lanes go out of range.
+__device__ __forceinline__ float dpre_fire(unsigned long long mF, unsigned long long mB, __amdgpu_buffer_rsrc_t rsrc,
+                                           int voff, int voff_next_row, int soff) {
+    int v;
+    asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(v) : "v"(voff), "v"(voff_next_row), "s"(mB));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(kOobOffset), "s"(mF));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, soff, 0));
+}
+__device__ __forceinline__ void dpre_next(DpreSeq& q, int RS, int padb, int stepb) {
+    int t, t2;
+    asm volatile("s_add_i32 %0, %0, 4\n\ts_add_i32 %1, %1, %6\n\ts_cmp_ge_i32 %0, %4\n\t"
+                 "s_cselect_b32 %2, %4, 0\n\ts_cselect_b32 %3, %5, 0\n\ts_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %3"
+                 : "+s"(q.c0), "+s"(q.soff), "=&s"(t), "=&s"(t2) : "s"(RS), "s"(padb), "s"(stepb) : "scc");
+}
+struct DpreGeo {       // wave-uniform constants of the dpre stream
+    int tw, RS, padb, stepb;
+};
+// all pieces of one step at once (prologue of a unit)
+__device__ __forceinline__ float dpre_step_now(DpreSeq& q, const DpreGeo& D, __amdgpu_buffer_rsrc_t rsrc, int voff,
+                                               int voff_next_row) {
+    int nA, nAF;
+    unsigned long long mF, mB;
+    dpre_counts(q, D.tw, D.RS, nA, nAF);
+    const unsigned long long mA = low_groups_mask(nA), mAF = low_groups_mask(nAF);
+    dpre_masks(mA, mAF, mF, mB);
+    const float b = dpre_fire(mF, mB, rsrc, voff, voff_next_row, q.soff);
+    dpre_next(q, D.RS, D.padb, D.stepb);
+    return b;
+}
+
+template <int KH, int KW, int CINP, int NCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int TAPS = KH * KW;
+    constexpr int ROWS = TAPS * CINP;
+    constexpr int Q = (ROWS + 63) / 64;
+    constexpr int NQP = 4 / NCH;             // waves sharing a cout chunk split the q's
+    constexpr int QW = (Q + NQP - 1) / NQP;  // q's (LDS fragments per step) of this wave
+    constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    constexpr int U = 12;                    // steps per unrolled window (U*QW is a multiple of 3, U of 4)
+    constexpr int XSTEP = 4 * PS * 4;        // LDS bytes from one step to the next
+    constexpr int PF = 3;                    // dpre prefetch distance in steps
+    constexpr int LA = (QW >= 2) ? 2 : 1;    // LDS fragments in flight ahead of the MFMAs
+    static_assert((U * QW) % 3 == 0 && U % 4 == 0, "window must keep the register rings in phase");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, qpart = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int co = cout0 + li;
+    const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;   // clamped: columns >= Cout are never written out
+    const int c4 = tid % TPP, sp = tid / TPP;
+    char* ldsb = reinterpret_cast<char*>(lds);
+
+    // per-lane LDS byte offset of (position kq of a step, the lane's tap / channels) for each of its q's
+    int xb[QW];
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        int R = 64 * q + 4 * li;  // first of the lane's 4 rows (all 4 share the tap since CINP % 4 == 0)
+        if (q >= Q || R >= ROWS) R = 0;
+        const int tap = R / CINP, ci = R % CINP;
+        xb[k] = ((kq + (tap / KW) * a.RS + (tap % KW)) * PS + ci) * 4;
+    }
+    // the whole tile buffer starts out as zeros: pad columns (never written by the scalar staging below) and
+    // the slots past a short tile that the last step may touch (their dpre operand is 0, they must be finite)
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int n16 = (a.zero_slot + 4) * PS / 4;     // (the host allocates 4 slots past the largest tile)
+        for (int i = tid; i < n16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
+    }
+    // scalar staging (see conv_pipe_kernel) when the channels fit exactly, else the generic stager
+    const bool lean = (a.Cin == CINP) && (a.RS >= PPP);
+    const int voff_lane = tid * 16;
+    const int wl_lane = (sp * PS + 4 * c4) * 4;
+    StageGeo SG;
+    const int JP = (a.RS + PPP - 1) / PPP;
+    SG.JP1 = __builtin_amdgcn_readfirstlane(JP - 1);
+    SG.rowfix_g = __builtin_amdgcn_readfirstlane((a.W - JP * PPP) * CINP * 4);
+    SG.rowfix_l = __builtin_amdgcn_readfirstlane((a.RS - JP * PPP) * PS * 4);
+    SG.m_first = uniform64(__ballot(sp >= a.pad_l));
+    SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
+    DpreGeo DG;
+    DG.tw = __builtin_amdgcn_readfirstlane(a.OW);
+    DG.RS = __builtin_amdgcn_readfirstlane(a.RS);
+    DG.padb = __builtin_amdgcn_readfirstlane((a.RS - a.OW) * a.Cout * 4);
+    DG.stepb = __builtin_amdgcn_readfirstlane(16 * a.Cout);
+    // lane offsets count from RS-OW pixels BEFORE the unit's first pixel (the buffer resource starts there; those
+    // bytes are never touched), so that both variants are non-negative: offsets are unsigned to the hardware
+    const int voff_bn = (kq * a.Cout + co_c) * 4;                    // lane whose position lies in the next tile row
+    const int voff_b = voff_bn + (a.RS - a.OW) * a.Cout * 4;         // lane in the row of the step's first position
+
+    f32x4 acc[QW][4];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[k][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    if (a.stagger) stagger_second_workgroup(a.stagger);
+    int u = u0;
+    while (u < u1) {
+        const int h = u % a.OH;
+        const int n = u / a.OH;
+        int th = a.TH;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - u < th) th = u1 - u;
+
+        lds_barrier();
+        if (lean) {
+            StageSeq qi, qc;
+            const int left = __builtin_amdgcn_readfirstlane((th + KH - 1) * JP);
+            const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;
+            qi.j = 0; qc.j = 0;
+            qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+            qc.off = 0;
+            qi.left = left; qc.left = left;
+            qi.thr = __builtin_amdgcn_readfirstlane(left - above);
+            qc.thr = 0;
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
+            stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        } else {
+            stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, -a.pad_l, a.RS, a.inv_rs,
+                             (th + KH - 1) * a.RS + (KW - 1), tid);
+        }
+        lds_barrier();
+
+        const int nsteps = (th * a.RS + 3) >> 2;
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.dpre) + (((size_t)n * a.OH + h) * a.OW - (a.RS - a.OW)) * a.Cout, 0,
+            (th * a.OW + (a.RS - a.OW)) * a.Cout * 4, 0x00020000);
+        DpreSeq dq;
+        dq.c0 = __builtin_amdgcn_readfirstlane(0);
+        dq.soff = __builtin_amdgcn_readfirstlane(0);
+        float bq[4];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) bq[j] = dpre_step_now(dq, DG, brs, voff_b, voff_bn);
+        bq[3] = 0.f;
+
+        int xw[QW];      // window base of each fragment stream
+#pragma unroll
+        for (int k = 0; k < QW; ++k) xw[k] = xb[k];
+        auto read_x = [&](int k, int uu) -> f32x4 { return *reinterpret_cast<const f32x4*>(ldsb + xw[k] + uu * XSTEP); };
+        f32x4 ring[3];
+        ring[0] = read_x(0, 0);
+        if (LA == 2) ring[1] = read_x(1 % QW, 1 / QW);
+
+        for (int s0 = 0; s0 < nsteps; s0 += U) {
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                if (s0 + uu < nsteps) {
+                    const float b = bq[uu % 4];      // dpre of this step, loaded PF steps ago
+                    bsum += b;
+                    int nA = 0, nAF = 0;
+                    unsigned long long mA = 0, mAF = 0, mF = 0, mB = 0;
+#pragma unroll
+                    for (int k = 0; k < QW; ++k) {
+                        const int idx = (uu * QW + k) % 3;
+                        const int kk = k + LA;
+                        ring[(idx + LA) % 3] = (kk < QW) ? read_x(kk, uu) : read_x(kk - QW, uu + 1);
+                        mfma4_wgrad(acc[k], ring[idx], b);
+                        // the dpre stream of step + PF: six small scalar pieces dealt out over the step's gaps
+#pragma unroll
+                        for (int pc = 0; pc < 6; ++pc) {
+                            if ((pc * QW) / 6 != k) continue;
+                            if (pc == 0) dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
+                            if (pc == 1) mA = low_groups_mask(nA);
+                            if (pc == 2) mAF = low_groups_mask(nAF);
+                            if (pc == 3) dpre_masks(mA, mAF, mF, mB);
+                            if (pc == 4) bq[(uu + PF) % 4] = dpre_fire(mF, mB, brs, voff_b, voff_bn, dq.soff);
+                            if (pc == 5) dpre_next(dq, DG.RS, DG.padb, DG.stepb);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < QW; ++k) xw[k] += U * XSTEP;
+        }
         u += th;
     }
 

@@ -311,7 +311,15 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
-    if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
+    // Linear-walk kernel for full-width tiles (see wgrad_lin_kernel); SRX_WGRAD_LIN=0 selects the cursor kernel (A/B).
+    static int use_lin = -1;
+    if (use_lin < 0) { const char* e = getenv("SRX_WGRAD_LIN"); use_lin = e ? atoi(e) : 1; }
+    const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
+                        (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
+    // (its last step may read up to 3 slots past the tile: they are allocated and zeroed, their dpre operand is 0)
+    const size_t lin_lds = p.lds_bytes + 4 * (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
+    if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
+    } else if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
                     p.nch);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));

@@ -1,0 +1,13 @@
+// Conv2DBackpropFilter, linear-walk kernel (full-width tiles): the 3x3 layers with 32 / 64 staged channels.
+#include "launchers.h"
+namespace srx {
+bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
+    SRX_WGRAD_LIN_CASE(3, 3, 64, 4, 2)
+    SRX_WGRAD_LIN_CASE(3, 3, 64, 2, 2)
+    SRX_WGRAD_LIN_CASE(3, 3, 64, 1, 2)
+    SRX_WGRAD_LIN_CASE(3, 3, 32, 4, 2)
+    SRX_WGRAD_LIN_CASE(3, 3, 32, 2, 2)
+    SRX_WGRAD_LIN_CASE(3, 3, 32, 1, 2)
+    return false;
+}
+}  // namespace srx

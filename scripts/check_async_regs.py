@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""ISA check for the kernels that issue loads from inline asm (the compiler does not know those loads are
+asynchronous): between such a load and the s_waitcnt / ds_write statement that consumes it, no other
+instruction may READ the destination registers (a compiler-made copy would copy stale data).
+
+Rule checked per kernel: for every `buffer_load_dword[x4] vD, ... offen` that sits in an inline-asm block
+(;;#ASMSTART .. ;;#ASMEND), scan forward until the first instruction inside a later asm block that mentions vD;
+any instruction outside asm blocks that reads vD before that is an error."""
+import re, sys
+
+def regs(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+def operands(line):
+    body = line.split(None, 1)
+    if len(body) < 2:
+        return []
+    return [t.strip() for t in re.split(r',\s*', body[1].split('//')[0])]
+
+bad = 0
+checked = 0
+for path in sys.argv[1:]:
+    lines = open(path).read().split('\n')
+    in_app = False
+    seq = []   # (text, in_app)
+    for l in lines:
+        t = l.strip()
+        if 'ASMSTART' in t:
+            in_app = True; continue
+        if 'ASMEND' in t:
+            in_app = False; continue
+        if l.startswith('\t') and t and not t.startswith(('.', ';')):
+            seq.append((t.split('//')[0].strip(), in_app))
+        elif t.endswith(':') and not t.startswith(('.L', ';')):
+            seq.append(('@' + t, False))      # kernel boundary
+    for i, (t, app) in enumerate(seq):
+        if not app or not t.startswith('buffer_load_dword'):
+            continue
+        d = regs(operands(t)[0])
+        checked += 1
+        for j in range(i + 1, min(i + 4000, len(seq))):
+            u, uapp = seq[j]
+            if u.startswith('@'):
+                break
+            ops = operands(u)
+            touched = set()
+            for o in ops:
+                touched |= regs(o)
+            if not (touched & d):
+                continue
+            if uapp:
+                break            # consumed (or re-loaded) by an asm statement: fine
+            # outside asm: writing the register is a bug too, reading certainly is
+            print('%s: %s  touches the destination of asm load "%s" before its consumer' % (path, u, t))
+            bad += 1
+            break
+print('%d asm loads checked, %d violations' % (checked, bad))
+sys.exit(1 if bad else 0)

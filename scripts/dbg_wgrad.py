@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Diagnostic: wgrad against a float64 torch reference, error broken down by tap / channel."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ml_super_resolution_amd import ops
+dev = torch.device('cuda')
+N, H, W, Ci, Co = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (2, 41, 41, 64, 3))]
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.rand((N, H, W, Ci), device=dev, generator=g) * 2 - 1
+dy = torch.rand((N, H, W, Co), device=dev, generator=g) * 2 - 1
+dw, db = ops.conv2d_bwd_filter(x, dy, (3, 3, Ci, Co), 'same')
+torch.cuda.synchronize()
+xd = x.double().permute(0, 3, 1, 2); dyd = dy.double().permute(0, 3, 1, 2)
+xp = torch.nn.functional.pad(xd, (1, 1, 1, 1))
+ref = torch.zeros((3, 3, Ci, Co), dtype=torch.float64, device=dev)
+for kh in range(3):
+    for kw in range(3):
+        ref[kh, kw] = torch.einsum('nchw,ndhw->cd', xp[:, :, kh:kh + H, kw:kw + W], dyd)
+err = (dw.double() - ref).abs()
+print('dw max abs err %.3e (ref max %.3e)' % (float(err.max()), float(ref.abs().max())))
+print('per tap max err:', [['%.1e' % float(err[kh, kw].max()) for kw in range(3)] for kh in range(3)])
+print('per cout max err:', ['%.1e' % float(err[:, :, :, c].max()) for c in range(min(Co, 8))])
+e_ci = err.amax(dim=(0, 1, 3))
+print('per cin max err (first 16):', ['%.1e' % float(v) for v in e_ci[:16]])
+dbr = dyd.sum(dim=(0, 2, 3))
+print('db max abs err %.3e' % float((db.double() - dbr).abs().max()))
