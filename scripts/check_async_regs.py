@@ -9,11 +9,13 @@ any instruction outside asm blocks that reads vD before that is an error."""
 import re, sys
 
 def regs(tok):
-    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    # VGPR n -> n, AGPR n -> 1000 + n
+    m = re.match(r'([va])\[(\d+):(\d+)\]', tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r'v(\d+)$', tok)
-    return {int(m.group(1))} if m else set()
+        base = 1000 if m.group(1) == 'a' else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.match(r'([va])(\d+)$', tok)
+    return {(1000 if m.group(1) == 'a' else 0) + int(m.group(2))} if m else set()
 
 def operands(line):
     body = line.split(None, 1)
@@ -34,7 +36,7 @@ for path in sys.argv[1:]:
         if 'ASMEND' in t:
             in_app = False; continue
         if l.startswith('\t') and t and not t.startswith(('.', ';')):
-            seq.append((t.split('//')[0].strip(), in_app))
+            seq.append((t, in_app))
         elif t.endswith(':') and not t.startswith(('.L', ';')):
             seq.append(('@' + t, False))      # kernel boundary
     for i, (t, app) in enumerate(seq):
@@ -46,10 +48,13 @@ for path in sys.argv[1:]:
             u, uapp = seq[j]
             if u.startswith('@'):
                 break
-            ops = operands(u)
             touched = set()
-            for o in ops:
-                touched |= regs(o)
+            for m in re.finditer(r'\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b', u):     # (also registers named in an asm comment)
+                if m.group(5) is not None:
+                    touched.add((1000 if m.group(4) == 'a' else 0) + int(m.group(5)))
+                else:
+                    base = 1000 if m.group(1) == 'a' else 0
+                    touched |= set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
             if not (touched & d):
                 continue
             if uapp:

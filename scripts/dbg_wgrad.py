@@ -25,3 +25,5 @@ e_ci = err.amax(dim=(0, 1, 3))
 print('per cin max err (first 16):', ['%.1e' % float(v) for v in e_ci[:16]])
 dbr = dyd.sum(dim=(0, 2, 3))
 print('db max abs err %.3e' % float((db.double() - dbr).abs().max()))
+dw2, db2 = ops.conv2d_bwd_filter(x, dy, (3, 3, Ci, Co), 'same')
+print('deterministic:', bool(torch.equal(dw, dw2) and torch.equal(db, db2)))
