@@ -163,12 +163,12 @@ def main():
             'fwd_ms': round(fwd_ms, 3),
             'train_step_tflops': round(train_tf, 2),
             'train_step_frac_of_fp32_mfma_peak': round(train_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<3,3,64,4> (3x3 64->64 fwd+bias+ReLU)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_pipe_kernel<3,3,64,4,fwd> (3x3 64->64 fwd+bias+ReLU)',
                          'achieved': round(achieved_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          # HBM bytes per launch from the PMC passes committed under profiles/ (2*FETCH_SIZE +
                          # WRITE_SIZE, gfx950 correction); algorithmic bytes are 220.3e6 (input + output once)
-                         'traffic': 2.582e8, 'traffic_source': 'profiles/r01_prof_conv_hbm_counters.csv',
+                         'traffic': 2.219e8, 'traffic_source': 'profiles/r01_prof_conv_hbm_counters.csv',
                          'launch_ms': round(mid_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -2,20 +2,22 @@
 // v_mfma_f32_16x16x4_f32.
 //
 // Design:
-//  * NHWC activations, HWIO filters, stride 1.  One persistent workgroup (4 waves) owns a
-//    contiguous range of output rows ("units"); two workgroups are resident per CU (<= 80 KiB
-//    LDS, <= 256 VGPRs each) so one stages its next tile while the other issues MFMAs.
-//  * A tile's input halo (TH+KH-1 rows) is staged ONCE into LDS with a padded pixel stride
-//    (Cin+4 floats) and explicit zero padding, then read KH*KW times; tap offsets become
+//  * NHWC activations, HWIO filters, stride 1.  A persistent workgroup (4 waves) owns a contiguous range
+//    of output rows ("units").  A tile's input halo (TH+KH-1 rows) is staged ONCE into LDS with a padded
+//    pixel stride (Cin+4 floats) and explicit zero padding, then read KH*KW times; tap offsets become
 //    ds_read immediates.
-//  * forward / dgrad: the layer's weights for a wave's 16 output channels are STATIONARY IN
-//    REGISTERS for the whole kernel (3x3x64 -> 144 VGPRs); MFMA A = weights (rows = Cout),
-//    B = pixels (cols), so each lane ends up holding 4 consecutive output channels of one pixel
-//    -> one 16-byte store.  Bias is the accumulator's initial value; activation / residual add /
-//    upstream activation-gradient mask are fused in the epilogue.
-//  * wgrad: the dW accumulators (144 VGPRs for 3x3x64 per 16 Cout) are stationary for the whole
-//    kernel; x comes from the same LDS halo tile, dpre straight from global (each element is used
-//    by exactly one wave).  Per-workgroup partials are reduced by a second, fixed-order kernel.
+//  * forward / dgrad: the layer's weights for a wave's 16 output channels are STATIONARY IN REGISTERS for
+//    the whole kernel (3x3x64 -> 144 registers); MFMA A = weights (rows = Cout), B = pixels (cols), so
+//    each lane ends up holding 4 consecutive output channels of one pixel -> one 16-byte store.
+//    Activation / residual add / upstream activation-gradient mask are fused in the epilogue.
+//      - conv_pipe_kernel (the 3x3 body layers): one workgroup per CU, weights in AGPRs, the tile
+//        double-buffered, everything that is not an MFMA done by scalar and memory instructions;
+//      - conv_mfma_kernel / conv_mfma_generic_kernel (all other shapes): two workgroups per CU that stage
+//        between their MFMA phases.
+//  * wgrad: the dW accumulators (144 VGPRs for 3x3x64 per 16 Cout) are stationary for the whole kernel;
+//    x comes from the same LDS halo tile, dpre straight from global (each element is used by exactly one
+//    wave).  Per-workgroup partials are reduced by a second, fixed-order kernel.  wgrad_lin_kernel walks
+//    the padded tile positions (VALU-free K loop), wgrad_mfma_kernel the real pixels with per-lane cursors.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
