@@ -228,6 +228,64 @@ class ConvStack(object):
             sd['opt_v'] = self.opt_v.detach().cpu()
         return sd
 
+    # ---- TensorFlow V2 checkpoints (tf.train.Saver format; tf_bundle.py) --------------------------
+    def tf_checkpoint_tensors(self, adam_betas=(0.9, 0.999)):
+        """{checkpoint key: ndarray} as tf.train.Saver would write this model: `<scope>/kernel`, `<scope>/bias`,
+        `global_step` (int64) and, when an optimizer has run, its slots: Adam `<var>/Adam`, `<var>/Adam_1`,
+        `beta1_power`, `beta2_power`; Momentum `<var>/Momentum`."""
+        import numpy as np
+        out = {k: v.detach().cpu().numpy() for k, v in self.variables().items()}
+        out['global_step'] = np.asarray(self.global_step, dtype=np.int64)
+        if self.opt_m is not None:
+            two = self.opt_v is not None
+            for i, s in enumerate(self.specs):
+                scope = s.scope or ('layer%d' % i)
+                for kind, view in (('kernel', self.kernel), ('bias', self.bias)):
+                    out['%s/%s/%s' % (scope, kind, 'Adam' if two else 'Momentum')] = view(i, self.opt_m).detach().cpu().numpy()
+                    if two:
+                        out['%s/%s/Adam_1' % (scope, kind)] = view(i, self.opt_v).detach().cpu().numpy()
+            if two:
+                out['beta1_power'] = np.asarray(adam_betas[0] ** self.global_step, dtype=np.float32)
+                out['beta2_power'] = np.asarray(adam_betas[1] ** self.global_step, dtype=np.float32)
+        return out
+
+    def save_tf_checkpoint(self, prefix, adam_betas=(0.9, 0.999)):
+        from . import tf_bundle
+        tf_bundle.save_checkpoint(prefix, self.tf_checkpoint_tensors(adam_betas))
+
+    def load_tf_checkpoint(self, prefix, with_optimizer=True):
+        """Restores kernels / biases (and global_step, optimizer slots when present) from a checkpoint written by
+        the reference's `tf.train.Saver` (vdsr/vdsr/experiment_train.py:100-121) or by save_tf_checkpoint."""
+        from . import tf_bundle
+        values = tf_bundle.load_checkpoint(prefix)
+        mine = self.variables()
+        missing = [k for k in mine if k not in values]
+        if missing:
+            raise KeyError('checkpoint %s lacks variables %s' % (prefix, missing[:4]))
+        self.load_variables({k: values[k] for k in mine})
+        if 'global_step' in values:
+            self.global_step = int(values['global_step'])
+        if not with_optimizer:
+            return
+        for slot, attr in (('Adam', 'opt_m'), ('Adam_1', 'opt_v'), ('Momentum', 'opt_m')):
+            names = ['%s/%s' % (k, slot) for k in mine]
+            if all(n in values for n in names):
+                buf = torch.zeros_like(self.params)
+                for i, s in enumerate(self.specs):
+                    scope = s.scope or ('layer%d' % i)
+                    self.kernel(i, buf).copy_(torch.as_tensor(values['%s/kernel/%s' % (scope, slot)]).to(self.device))
+                    self.bias(i, buf).copy_(torch.as_tensor(values['%s/bias/%s' % (scope, slot)]).to(self.device))
+                setattr(self, attr, buf)
+
+    def load_checkpoint(self, path):
+        """`path`: a TensorFlow V2 checkpoint prefix (as the reference's --ckpt_path, e.g. .../model.ckpt-25600)
+        or a state dict saved with torch.save(stack.state_dict())."""
+        from . import tf_bundle
+        if tf_bundle.is_checkpoint_prefix(path):
+            self.load_tf_checkpoint(path)
+        else:
+            self.load_state_dict(torch.load(path))
+
     def load_state_dict(self, sd):
         self.params.copy_(sd['params'].to(self.device))
         self.global_step = int(sd['global_step'])

@@ -124,7 +124,14 @@ def build_model(lr_source, scaling_factor=3, hr_target=None, device='cuda', seed
 
 
 def extract_weights(meta_path, ckpt_path):
-    """{variable name: ndarray} for every trainable variable (model_espcn.py:150-166)."""
+    """{variable name: ndarray} for every trainable variable (model_espcn.py:150-166).  `ckpt_path` is either a
+    TensorFlow V2 checkpoint prefix (read by tf_bundle, no TensorFlow needed; `meta_path` is not used: the
+    trainable variables are the `f{1,2,3}/{kernel,bias}` entries) or an .npz written by EspcnModel.save."""
+    from .. import tf_bundle
+    if tf_bundle.is_checkpoint_prefix(ckpt_path):
+        values = tf_bundle.load_checkpoint(ckpt_path)
+        return {k + ':0': v for k, v in values.items()
+                if k.count('/') == 1 and k.split('/')[1] in ('kernel', 'bias')}
     z = np.load(ckpt_path)
     return {k: z[k] for k in z.files if k.endswith(':0')}
 

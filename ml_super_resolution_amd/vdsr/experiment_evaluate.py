@@ -35,7 +35,7 @@ def main(argv=None):
     FLAGS = ap.parse_args(argv)
     device = torch.device('cuda')
     model = model_vdsr.VdsrModel(FLAGS.num_layers, device=device)
-    model.stack.load_state_dict(torch.load(FLAGS.ckpt_path))
+    model.stack.load_checkpoint(FLAGS.ckpt_path)      # TF V2 prefix (reference checkpoints) or .pt
     names = [n for n in sorted(os.listdir(FLAGS.hd_image_dir_path)) if n[-4:] in ['.png', '.jpg', '.bmp']]
     sd_psnrs, sr_psnrs, sd_ssims, sr_ssims, total = [], [], [], [], 0.0
     for n in names:

@@ -27,7 +27,7 @@ def main(argv=None):
     FLAGS = ap.parse_args(argv)
     device = torch.device('cuda')
     model = model_vdsr.VdsrModel(FLAGS.num_layers, device=device)
-    model.stack.load_state_dict(torch.load(FLAGS.ckpt_path))
+    model.stack.load_checkpoint(FLAGS.ckpt_path)      # TF V2 prefix (reference checkpoints) or .pt
     hd = np.asarray(Image.open(FLAGS.hd_image_path).convert('RGB')).astype(np.float32) / 255.0
     if FLAGS.ground_truth_mode:
         sd = dataset.hd_image_to_sd_image(hd, FLAGS.scaling_factor)

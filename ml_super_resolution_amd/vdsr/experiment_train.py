@@ -47,8 +47,14 @@ def parse_flags(argv=None):
 def latest_checkpoint(ckpt_path):
     if not ckpt_path:
         return None
-    found = glob.glob(os.path.join(ckpt_path, 'model.ckpt-*.pt'))
-    return max(found, key=lambda p: int(p.rsplit('-', 1)[1][:-3])) if found else None
+    # TensorFlow V2 checkpoints (model.ckpt-N.index + .data-*: what the reference's Saver writes and what this
+    # script writes too) and, for older runs of this script, torch state dicts (model.ckpt-N.pt)
+    found = {}
+    for p in glob.glob(os.path.join(ckpt_path, 'model.ckpt-*.index')):
+        found[int(p[:-6].rsplit('-', 1)[1])] = p[:-6]
+    for p in glob.glob(os.path.join(ckpt_path, 'model.ckpt-*.pt')):
+        found.setdefault(int(p.rsplit('-', 1)[1][:-3]), p)
+    return found[max(found)] if found else None
 
 
 def main(argv=None):
@@ -67,7 +73,7 @@ def main(argv=None):
     model = model_vdsr.VdsrModel(FLAGS.num_layers, FLAGS.use_adam, device=device)
     source = latest_checkpoint(FLAGS.ckpt_path)
     if source is not None:
-        model.stack.load_state_dict(torch.load(source))
+        model.stack.load_checkpoint(source)
     if world > 1:
         srx_dist.attach(model.stack, world)
 
@@ -90,7 +96,8 @@ def main(argv=None):
         if step == FLAGS.stop_training_at_k_step:
             if FLAGS.ckpt_path and rank == 0:
                 os.makedirs(FLAGS.ckpt_path, exist_ok=True)
-                torch.save(model.stack.state_dict(), os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d.pt' % step))
+                # the reference: saver.save(session, ckpt_path/model.ckpt, global_step) (experiment_train.py:100-121)
+                model.stack.save_tf_checkpoint(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d' % step))
             break
         lr = FLAGS.initial_learning_rate * (FLAGS.learning_rate_decay_factor ** (step // FLAGS.learning_rate_decay_steps))
         sd_images, hd_images = next(batches)
