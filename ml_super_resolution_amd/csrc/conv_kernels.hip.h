@@ -779,6 +779,9 @@ __device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const
     stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
 }
 
+#ifndef SRX_WG_NB
+#define SRX_WG_NB 6
+#endif
 // a whole tile with NB loads in flight (kernels that stage between their MFMA phases)
 template <int CINP, int NB>
 __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
@@ -1674,7 +1677,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
             qc.thr = 0;
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
-            stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
+            stage_tile_scalar<CINP, SRX_WG_NB>(qi, qc, SG, xrs, voff_lane, wl_lane);
         } else {
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, -a.pad_l, a.RS, a.inv_rs,
                              (th + KH - 1) * a.RS + (KW - 1), tid);
