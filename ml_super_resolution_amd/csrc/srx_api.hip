@@ -143,7 +143,10 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // Epilogue forms it implements (integer-VALU only): none / ReLU, ReLU-gradient mask, residual add (+ ReLU).
     const bool epi_ok = (a.act == ACT_NONE || a.act == ACT_RELU) && !(a.mask && a.skip) && !(wt && a.skip) && !(!wt && a.mask) &&
                         (!a.mask || (a.mask_act == ACT_RELU && a.act == ACT_NONE && !a.post_relu));
-    const bool pipe_ok = epi_ok && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && 16 * npart <= a.OW && (a.Cout & 3) == 0 &&
+    // (p.RS == W + pad_l: the only pad slots of a tile row are the pad_l leading ones, which the scalar staging
+    // never writes; a dgrad of a VALID layer has trailing pad slots inside the row as well and stays on path 0)
+    const bool pipe_ok = epi_ok && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
+                         16 * npart <= a.OW && (a.Cout & 3) == 0 &&
                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     if (g_use_pipe && p.cinp >= 16 && pipe_ok) {
         const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
@@ -314,7 +317,7 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     // Linear-walk kernel for full-width tiles (see wgrad_lin_kernel); SRX_WGRAD_LIN=0 selects the cursor kernel (A/B).
     static int use_lin = -1;
     if (use_lin < 0) { const char* e = getenv("SRX_WGRAD_LIN"); use_lin = e ? atoi(e) : 1; }
-    const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
+    const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && p.RS == d->W + pl && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
     // (its last step may read up to 3 slots past the tile: they are allocated and zeroed, their dpre operand is 0)
     const size_t lin_lds = p.lds_bytes + 4 * (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;

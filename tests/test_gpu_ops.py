@@ -75,6 +75,14 @@ SHAPES = [
     (1, 25, 25, 1, 64, 32, 'VALID', 'relu'),
     (1, 25, 25, 5, 32, 3, 'VALID', 'tanh'),
     (1, 1, 1, 3, 64, 64, 'SAME', 'relu'),        # degenerate 1x1 image
+    # the scalar-driven kernels (conv_pipe_kernel / wgrad_lin_kernel): workgroup ranges that cut images, short
+    # last units, VALID geometry (no pad column forward, two pad columns in dgrad, two fake positions per row in
+    # wgrad), 32 staged channels, 32 / 48 output channels (2 / 4 channel chunks, ragged last chunk)
+    (37, 41, 41, 3, 64, 64, 'SAME', 'relu'),
+    (2, 30, 30, 3, 64, 64, 'VALID', 'relu'),
+    (4, 23, 57, 3, 64, 32, 'SAME', None),
+    (3, 19, 40, 3, 32, 32, 'SAME', 'relu'),
+    (2, 26, 35, 3, 64, 48, 'VALID', None),
     (2, 7, 3, 3, 3, 64, 'SAME', 'relu'),
 ]
 
