@@ -83,6 +83,9 @@ SHAPES = [
     (4, 23, 57, 3, 64, 32, 'SAME', None),
     (3, 19, 40, 3, 32, 32, 'SAME', 'relu'),
     (2, 26, 35, 3, 64, 48, 'VALID', None),
+    (1, 3, 16, 3, 64, 64, 'SAME', 'relu'),       # narrowest / shortest images the pipelined kernel accepts
+    (2, 100, 16, 3, 64, 64, 'SAME', None),
+    (64, 5, 17, 3, 64, 64, 'SAME', 'relu'),      # many tiny images per workgroup
     (2, 7, 3, 3, 3, 64, 'SAME', 'relu'),
 ]
 
