@@ -924,10 +924,7 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     constexpr int NG = CINP / 16;
     constexpr int NBLK = KH * KW * NG;
     constexpr int NST = (NBLK / 2 < 6) ? NBLK / 2 : 6;   // staging passes threaded through this group
-    // first epilogue block.  With an aux operand the epilogue waits for its (compiler-issued) aux loads, and the
-    // compiler's counted wait then also covers the younger asm-issued staging loads it does not know about:
-    // the epilogue is placed behind the staging writes, where those have landed anyway.
-    constexpr int E0 = (AUX == 0) ? NST : ((NBLK / 2 + NST < NBLK - MAXG) ? NBLK / 2 + NST : NBLK - MAXG);
+    constexpr int E0 = NST;                               // first epilogue block
     constexpr int A0 = NST + MAXG;                        // address block
     constexpr int TSTEP = 16 * PS * 4 * NPART;            // table bytes from one sub-tile of the wave to the next
     constexpr int PPP = 256 / (CINP / 4);
