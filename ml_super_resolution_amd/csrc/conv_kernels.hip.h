@@ -687,6 +687,12 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// a buffer resource that provably lives in SGPRs (it is an "s" operand of asm statements)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p, int num_records) {
+    const unsigned long long q = uniform64((unsigned long long)reinterpret_cast<uintptr_t>(p));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(static_cast<uintptr_t>(q)), 0,
+                                             __builtin_amdgcn_readfirstlane(num_records), 0x00020000);
+}
 struct StageGeo {      // wave-uniform constants of the staging sequence
     int JP1;           // passes per tile row, minus 1
     int rowfix_g, rowfix_l;  // extra bytes (beyond the constant pass step) when the next pass starts a new row: image, LDS
@@ -728,6 +734,19 @@ __device__ __forceinline__ void stage_mask_b(const StageSeq& q, unsigned long lo
                  "s_cmp_gt_i32 %3, %4\n\t"
                  "s_cselect_b32 %1, 0x7ff00000, %5"
                  : "+s"(m), "=&s"(so) : "s"(t), "s"(q.left), "s"(q.thr), "s"(q.off) : "scc");
+}
+// EXEC mask of a cursor's pass in one piece (commit side of kernels that do not keep the issue-time mask)
+__device__ __forceinline__ unsigned long long stage_mask_full(const StageSeq& q, const StageGeo& G) {
+    unsigned long long m, t;
+    asm volatile("s_cmp_eq_u32 %2, 0\n\t"
+                 "s_cselect_b64 %0, %4, -1\n\t"
+                 "s_cmp_eq_u32 %2, %3\n\t"
+                 "s_cselect_b64 %1, %5, -1\n\t"
+                 "s_and_b64 %0, %0, %1\n\t"
+                 "s_cmp_gt_i32 %6, 0\n\t"
+                 "s_cselect_b64 %0, %0, 0"
+                 : "=&s"(m), "=&s"(t) : "s"(q.j), "s"(G.JP1), "s"(G.m_first), "s"(G.m_last), "s"(q.left) : "scc");
+    return m;
 }
 // (3) the load: 16 bytes per active lane, no VALU
 __device__ __forceinline__ f32x4 stage_fire(unsigned long long m, int so, __amdgpu_buffer_rsrc_t rsrc, int voff_lane) {
@@ -1564,6 +1583,17 @@ __device__ __forceinline__ void dpre_next(DpreSeq& q, int RS, int padb, int step
                  "s_cselect_b32 %2, %4, 0\n\ts_cselect_b32 %3, %5, 0\n\ts_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %3"
                  : "+s"(q.c0), "+s"(q.soff), "=&s"(t), "=&s"(t2) : "s"(RS), "s"(padb), "s"(stepb) : "scc");
 }
+// SALU instructions are not free in bulk either (about 4 per gap of the MFMA stream are): most steps lie wholly
+// inside one tile row, where the masks are empty and the cursor simply moves on -- those take a short path
+// behind one wave-uniform branch.
+__device__ __forceinline__ int dpre_is_plain(const DpreSeq& q, int tw) {     // all four positions real and in this row
+    int t;
+    asm volatile("s_add_i32 %0, %1, 4\n\ts_cmp_le_i32 %0, %2\n\ts_cselect_b32 %0, 1, 0" : "=&s"(t) : "s"(q.c0), "s"(tw) : "scc");
+    return t;
+}
+__device__ __forceinline__ void dpre_next_plain(DpreSeq& q, int stepb) {
+    asm volatile("s_add_i32 %0, %0, 4\n\ts_add_i32 %1, %1, %2" : "+s"(q.c0), "+s"(q.soff) : "s"(stepb) : "scc");
+}
 struct DpreGeo {       // wave-uniform constants of the dpre stream
     int tw, RS, padb, stepb;
 };
@@ -1593,8 +1623,12 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     constexpr int U = 12;                    // steps per unrolled window (U*QW is a multiple of 3, U of 4)
     constexpr int XSTEP = 4 * PS * 4;        // LDS bytes from one step to the next
     constexpr int PF = 3;                    // dpre prefetch distance in steps
-    constexpr int LA = (QW >= 2) ? 2 : 1;    // LDS fragments in flight ahead of the MFMAs
-    static_assert((U * QW) % 3 == 0 && U % 4 == 0, "window must keep the register rings in phase");
+#ifndef SRX_WG_LA
+#define SRX_WG_LA 2
+#endif
+    constexpr int LA = (QW >= 2) ? ((U * QW) % (SRX_WG_LA + 1) == 0 ? SRX_WG_LA : 2) : 1;    // LDS fragments in flight ahead of the MFMAs
+    constexpr int RN = LA + 1;               // fragment ring
+    static_assert((U * QW) % RN == 0 && U % 4 == 0, "window must keep the register rings in phase");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1700,9 +1734,9 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
 #pragma unroll
         for (int k = 0; k < QW; ++k) xw[k] = xb[k];
         auto read_x = [&](int k, int uu) -> f32x4 { return *reinterpret_cast<const f32x4*>(ldsb + xw[k] + uu * XSTEP); };
-        f32x4 ring[3];
-        ring[0] = read_x(0, 0);
-        if (LA == 2) ring[1] = read_x(1 % QW, 1 / QW);
+        f32x4 ring[RN];
+#pragma unroll
+        for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
 
         for (int s0 = 0; s0 < nsteps; s0 += U) {
 #pragma unroll
@@ -1714,9 +1748,9 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
                     unsigned long long mA = 0, mAF = 0, mF = 0, mB = 0;
 #pragma unroll
                     for (int k = 0; k < QW; ++k) {
-                        const int idx = (uu * QW + k) % 3;
+                        const int idx = (uu * QW + k) % RN;
                         const int kk = k + LA;
-                        ring[(idx + LA) % 3] = (kk < QW) ? read_x(kk, uu) : read_x(kk - QW, uu + 1);
+                        ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
                         mfma4_wgrad(acc[k], ring[idx], b);
                         // the dpre stream of step + PF: six small scalar pieces dealt out over the step's gaps
 #pragma unroll
@@ -1741,6 +1775,317 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     // MFMA results are read by VALU / stores next
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- write this workgroup's partial
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 64 * q + 4 * (4 * kq + r) + g;
+                const int tap = R / CINP, ci = R % CINP;
+                if (R < ROWS && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgrad, linear walk, ONE workgroup per CU (the 64 -> 64 body layers).  Same K loop as wgrad_lin_kernel, but
+// the tile is double-buffered in LDS and the NEXT tile's staging passes ride on the steps of the running
+// one, as in conv_pipe_kernel; the dpre operands are fetched a whole window (16 steps) ahead.
+//
+// All loads of the step loop are issued from inline asm and waited for by hand (mixing them with
+// compiler-visible loads would make the compiler's counted waits cover the youngest asm loads too).  An
+// asm-issued load is asynchronous behind the compiler's back, so:
+//   * its consumer sits in the same straight-line code (the unrolled window): no such value is live across
+//     a branch or a loop back-edge, where the compiler could copy the register before the data has arrived
+//     (at window / unit boundaries the values pass through an s_waitcnt statement that names them);
+//   * it is parked in AGPRs: the 144 accumulators fill the VGPRs, and an "=a" / "=v" constraint only fixes
+//     the register class AT the statement -- with spare VGPRs the compiler moved such a value to a VGPR
+//     right after issue (seen in the smaller instances, which therefore stay on wgrad_lin_kernel);
+//   * scripts/check_async_regs.py (make check) rejects any build in which an instruction touches such a
+//     register between the load and its consumer.
+// Distances: a staging load is written to LDS 8 steps (~9 k cycles, ~4 us) after its issue, a dpre value is
+// used 8..23 steps after its issue -- activations come from HBM here, a batch of staging loads was measured
+// to take ~2.5 us in wgrad_lin_kernel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 stage_fire_a(unsigned long long m, int so, __amdgpu_buffer_rsrc_t rsrc, int voff_lane) {
+    f32x4 v;
+    asm volatile("s_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen\n\ts_mov_b64 exec, -1"
+                 : "=&a"(v) : "v"(voff_lane), "s"(rsrc), "s"(so), "s"(m) : "memory");
+    return v;
+}
+#define SRX_COMMIT_ASM_A(N)                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_add_u32 %0, %3, %4\n\ts_mov_b64 exec, %2\n\tds_write_b128 %0, %1\n\ts_mov_b64 exec, -1" \
+                 : "=&v"(addr) : "a"(v), "s"(m), "s"(q.off), "v"(wl_lane) : "memory")
+__device__ __forceinline__ void stage_commit_a(int pend, const StageSeq& q, unsigned long long m, int wl_lane, const f32x4 v) {
+    int addr;
+    if (pend >= 14) SRX_COMMIT_ASM_A(14);
+    else if (pend == 12) SRX_COMMIT_ASM_A(12);
+    else if (pend == 10) SRX_COMMIT_ASM_A(10);
+    else if (pend == 8) SRX_COMMIT_ASM_A(8);
+    else if (pend == 6) SRX_COMMIT_ASM_A(6);
+    else if (pend == 4) SRX_COMMIT_ASM_A(4);
+    else if (pend == 2) SRX_COMMIT_ASM_A(2);
+    else SRX_COMMIT_ASM_A(0);
+}
+__device__ __forceinline__ float dpre_fire_a(unsigned long long mF, unsigned long long mB, __amdgpu_buffer_rsrc_t rsrc,
+                                             int voff, int voff_next_row, int soff) {
+    int v;
+    float b;
+    asm volatile("v_cndmask_b32 %1, %2, %3, %4\n\t"
+                 "v_cndmask_b32 %1, %1, %5, %6\n\t"
+                 "buffer_load_dword %0, %1, %7, %8 offen"
+                 : "=&a"(b), "=&v"(v) : "v"(voff), "v"(voff_next_row), "s"(mB), "v"(kOobOffset), "s"(mF), "s"(rsrc), "s"(soff)
+                 : "memory");
+    return b;
+}
+
+template <int KH, int KW, int CINP, int NCH>
+__global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int TAPS = KH * KW;
+    constexpr int ROWS = TAPS * CINP;
+    constexpr int Q = (ROWS + 63) / 64;
+    constexpr int NQP = 4 / NCH;
+    constexpr int QW = (Q + NQP - 1) / NQP;
+    constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    constexpr int U = 16;                    // steps per unrolled window
+    constexpr int NSW = U / 2;               // staging passes per full window: loads in its first half, LDS writes in its second
+    constexpr int XSTEP = 4 * PS * 4;        // LDS bytes from one step to the next
+    constexpr int LA = 2, RN = 3;            // LDS fragments in flight ahead of the MFMAs / fragment ring
+    static_assert(QW * 16 >= 128, "AGPR parking assumes the accumulators fill the VGPRs (see above)");
+    static_assert((U * QW) % RN == 0, "window must keep the fragment ring in phase");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, qpart = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int co = cout0 + li;
+    const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;
+    const int c4 = tid % TPP, sp = tid / TPP;
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int buf_bytes = (a.zero_slot + 4) * PS * 4;   // (the host allocates 4 slots past the largest tile, per buffer)
+
+    // per-lane LDS byte address of (position kq of the running window's first step, the lane's tap / channels)
+    // (absolute 32-bit LDS addresses, read through address_space(3) pointers: with generic pointers or offsets from
+    // `lds` the compiler re-adds the LDS base in front of every read once the bases are opaque to it)
+    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+    const int lds_base = (int)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+    int xw[QW];
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        int R = 64 * q + 4 * li;
+        if (q >= Q || R >= ROWS) R = 0;
+        const int tap = R / CINP, ci = R % CINP;
+        xw[k] = lds_base + ((kq + (tap / KW) * a.RS + (tap % KW)) * PS + ci) * 4;
+    }
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 2 * buf_bytes / 16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
+    }
+    const int voff_lane = tid * 16;
+    const int wl_lane = (sp * PS + 4 * c4) * 4;
+    StageGeo SG;
+    const int JP = (a.RS + PPP - 1) / PPP;
+    SG.JP1 = __builtin_amdgcn_readfirstlane(JP - 1);
+    SG.rowfix_g = __builtin_amdgcn_readfirstlane((a.W - JP * PPP) * CINP * 4);
+    SG.rowfix_l = __builtin_amdgcn_readfirstlane((a.RS - JP * PPP) * PS * 4);
+    SG.m_first = uniform64(__ballot(sp >= a.pad_l));
+    SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
+    DpreGeo DG;
+    DG.tw = __builtin_amdgcn_readfirstlane(a.OW);
+    DG.RS = __builtin_amdgcn_readfirstlane(a.RS);
+    DG.padb = __builtin_amdgcn_readfirstlane((a.RS - a.OW) * a.Cout * 4);
+    DG.stepb = __builtin_amdgcn_readfirstlane(16 * a.Cout);
+    const int voff_bn = (kq * a.Cout + co_c) * 4;
+    const int voff_b = voff_bn + (a.RS - a.OW) * a.Cout * 4;
+
+    f32x4 acc[QW][4];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[k][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+
+    auto tile_of = [&](int uu_, int& n, int& h, int& th) {
+        h = uu_ % a.OH;
+        n = uu_ / a.OH;
+        th = a.TH;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - uu_ < th) th = u1 - uu_;
+    };
+    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int buf, bool active) {
+        const int left = __builtin_amdgcn_readfirstlane(active ? (th + KH - 1) * JP : 0);
+        const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;
+        qi.j = 0; qc.j = 0;
+        qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+        qc.off = __builtin_amdgcn_readfirstlane(buf * buf_bytes);
+        qi.left = left; qc.left = left;
+        qi.thr = __builtin_amdgcn_readfirstlane(left - above);
+        qc.thr = 0;
+    };
+    auto x_rsrc = [&](int n) {
+        return uniform_rsrc(a.x + ((size_t)n * a.H * a.W - a.pad_l) * CINP, (a.H * a.W + a.pad_l) * CINP * 4);
+    };
+    auto b_rsrc = [&](int n, int h, int th) {
+        return uniform_rsrc(a.dpre + (((size_t)n * a.OH + h) * a.OW - (a.RS - a.OW)) * a.Cout,
+                            (th * a.OW + (a.RS - a.OW)) * a.Cout * 4);
+    };
+
+    // dpre operands: bcur[] = the running window's (VGPRs), bnext[] = the next window's (in flight, AGPRs)
+    float bcur[U], bnext[U];
+    DpreSeq dq;
+    // a unit's first window, all at once: ordinary (compiler-visible) loads -- these ARE in flight across the
+    // staging drain loop and the barrier
+    auto dpre_window_now = [&](__amdgpu_buffer_rsrc_t brs) {
+        dq.c0 = __builtin_amdgcn_readfirstlane(0);
+        dq.soff = __builtin_amdgcn_readfirstlane(0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) bnext[j] = dpre_step_now(dq, DG, brs, voff_b, voff_bn);
+    };
+#define SRX_TAKE_OVER_B()                                                                                          \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0) ; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15"                  \
+                     : "+a"(bnext[0]), "+a"(bnext[1]), "+a"(bnext[2]), "+a"(bnext[3]), "+a"(bnext[4]), "+a"(bnext[5]), \
+                       "+a"(bnext[6]), "+a"(bnext[7]), "+a"(bnext[8]), "+a"(bnext[9]), "+a"(bnext[10]),            \
+                       "+a"(bnext[11]), "+a"(bnext[12]), "+a"(bnext[13]), "+a"(bnext[14]), "+a"(bnext[15]));       \
+        _Pragma("unroll") for (int j = 0; j < U; ++j)                                                              \
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(bcur[j]) : "a"(bnext[j]));   /* (here, not next to the MFMA that uses it) */ \
+    } while (0)
+    static_assert(U == 16, "SRX_TAKE_OVER_B names 16 registers");
+
+    int u = u0;
+    int n, h, th;
+    tile_of(u, n, h, th);
+    __syncthreads();
+    {
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h, th, 0, true);
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, x_rsrc(n), voff_lane, wl_lane);
+        dpre_window_now(b_rsrc(n, h, th));
+        lds_barrier();
+        SRX_TAKE_OVER_B();
+    }
+    int cur_buf = 0;
+    while (u < u1) {
+        tile_of(u, n, h, th);
+        const int un_ = u + th;
+        const bool has_next = un_ < u1;
+        int n2 = n, h2 = h, th2 = th;
+        if (has_next) tile_of(un_, n2, h2, th2);
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h2, th2, cur_buf ^ 1, has_next);
+        const __amdgpu_buffer_rsrc_t xrs = x_rsrc(n2);
+        const __amdgpu_buffer_rsrc_t brs = b_rsrc(n, h, th);
+
+        const int nsteps = (th * a.RS + 3) >> 2;
+        auto read_x = [&](int k, int uu) -> f32x4 { return *(lds_f32x4*)(uintptr_t)(unsigned)(xw[k] + uu * XSTEP); };
+        f32x4 ring[RN];
+#pragma unroll
+        for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
+
+        for (int s0 = 0; s0 < nsteps; s0 += U) {
+            // Only FULL windows carry extra work -- the next window's dpre loads (two steps' worth in each of the
+            // first U/2 steps) and NSW staging passes of the next tile: every asm load then has its consumer in
+            // the same straight-line code, and the number of memory operations between the two, which the
+            // s_waitcnt of an LDS write relies on, is known.  ONE loop body for full and partial windows, the
+            // extras behind wave-uniform tests: two bodies make the register allocator give the 144
+            // accumulators two homes and copy them at every window.
+            const bool fullw = (s0 + U <= nsteps);
+            f32x4 stg[NSW];
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                if (s0 + uu < nsteps) {
+                    const float b = bcur[uu];
+                    bsum += b;
+                    int nA = 0, nAF = 0;
+                    unsigned long long mA = 0, mAF = 0, mF = 0, mB = 0;
+                    unsigned long long smk = 0, smt = 0;
+                    int sso = 0;
+#pragma unroll
+                    for (int k = 0; k < QW; ++k) {
+                        const int idx = (uu * QW + k) % RN;
+                        const int kk = k + LA;
+                        ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
+                        mfma4_wgrad(acc[k], ring[idx], b);
+                        if (k == 0 && uu >= NSW && fullw) {
+                            // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
+                            // count: the two dpre loads of each first-half step after it.
+                            const unsigned long long m = stage_mask_full(qc, SG);
+                            stage_commit_a(2 * (NSW - 1 - (uu - NSW)), qc, m, wl_lane, stg[uu - NSW]);
+                            stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
+                        }
+                        if (uu < U / 2 && fullw) {
+                            // dpre of steps 2uu, 2uu+1 of the next window, at two gaps of the step: masks + load + cursor
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                if (k != (half == 0 ? 1 : 6)) continue;
+                                // (the load itself stays outside the branch: an asm-loaded value must not pass a merge point)
+                                const int so = dq.soff;
+                                if (dpre_is_plain(dq, DG.tw)) {
+                                    mF = 0; mB = 0;
+                                    dpre_next_plain(dq, DG.stepb);
+                                } else {
+                                    dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
+                                    mA = low_groups_mask(nA);
+                                    mAF = low_groups_mask(nAF);
+                                    dpre_masks(mA, mAF, mF, mB);
+                                    dpre_next(dq, DG.RS, DG.padb, DG.stepb);
+                                }
+                                bnext[2 * uu + half] = dpre_fire_a(mF, mB, brs, voff_b, voff_bn, so);
+                            }
+                            // one pass of the next tile, in three pieces
+                            if (k == 3) stage_mask_a(qi, SG, smk, smt);
+                            if (k == 4) stage_mask_b(qi, smk, smt, sso);
+                            if (k == QW - 1) {
+                                stg[uu] = stage_fire_a(smk, sso, xrs, voff_lane);
+                                stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);
+                            }
+                        }
+                    }
+                }
+            }
+            if (fullw) SRX_TAKE_OVER_B();
+            // (opaque adds: left to itself the compiler keeps the window offset in an SGPR and adds it to the nine
+            // bases in front of every LDS read -- one VALU instruction per fragment instead of nine per window)
+#pragma unroll
+            for (int k = 0; k < QW; ++k) { xw[k] += U * XSTEP; SRX_PIN(xw[k]); }
+        }
+        {
+            // back to step 0, in the other buffer
+            const int nwin = (nsteps + U - 1) / U;
+            const int back = __builtin_amdgcn_readfirstlane((cur_buf ? -buf_bytes : buf_bytes) - nwin * U * XSTEP);
+#pragma unroll
+            for (int k = 0; k < QW; ++k) { xw[k] += back; SRX_PIN(xw[k]); }
+        }
+        // the next unit's first dpre window travels while the rest of its tile is staged
+        if (has_next) dpre_window_now(b_rsrc(n2, h2, th2));
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        lds_barrier();
+        SRX_TAKE_OVER_B();      // (here, not at the top of the loop: no load may be in flight across the back-edge)
+        cur_buf ^= 1;
+        u = un_;
+    }
+#undef SRX_TAKE_OVER_B
+
+    // MFMA results are read by VALU / stores next
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
     for (int k = 0; k < QW; ++k) {

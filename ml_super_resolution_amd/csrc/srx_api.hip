@@ -321,12 +321,25 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
     // (its last step may read up to 3 slots past the tile: they are allocated and zeroed, their dpre operand is 0)
     const size_t lin_lds = p.lds_bytes + 4 * (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
-    if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
+    // one workgroup per CU, two tile buffers (wgrad_pipe_kernel): exact-fit channels, a row stride of at least one pass;
+    // SRX_WGRAD_PIPE=0 keeps the two-workgroup kernel (A/B)
+    static int use_wpipe = -1;
+    if (use_wpipe < 0) { const char* e = getenv("SRX_WGRAD_PIPE"); use_wpipe = e ? atoi(e) : 1; }
+    const int wppp = (p.cinp >= 16) ? 256 / (p.cinp / 4) : 256;
+    int wgrid = p.grid;
+    bool wdone = false;
+    if (use_wpipe && lin_ok && d->Cin == p.cinp && p.RS >= wppp && 2 * lin_lds <= 160 * 1024) {
+        wgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+        wdone = launch_wgrad_pipe(k, a, wgrid, 2 * lin_lds, s, &err);
+        if (!wdone) wgrid = p.grid;
+    }
+    if (wdone) {
+    } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
     } else if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
                     p.nch);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
-    err = launch_reduce_partials(a.part, p.grid, a.part_stride, (int)wn, d->Cout, dw, dbias, w_for_decay, wd_scale, s);
+    err = launch_reduce_partials(a.part, wgrid, a.part_stride, (int)wn, d->Cout, dw, dbias, w_for_decay, wd_scale, s);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "reduce launch failed: %s", hipGetErrorString(err));
     return SRX_OK;
 }

@@ -48,19 +48,30 @@ for path in sys.argv[1:]:
             u, uapp = seq[j]
             if u.startswith('@'):
                 break
-            touched = set()
-            for m in re.finditer(r'\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b', u):     # (also registers named in an asm comment)
-                if m.group(5) is not None:
-                    touched.add((1000 if m.group(4) == 'a' else 0) + int(m.group(5)))
-                else:
-                    base = 1000 if m.group(1) == 'a' else 0
-                    touched |= set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
-            if not (touched & d):
+            # registers the instruction READS: everything but the destination operand of instructions that have one
+            body_txt = u.split(None, 1)[1] if ' ' in u else ''
+            opcode = u.split()[0]
+            has_dest = opcode.startswith(('v_', 'buffer_load', 'global_load', 'ds_read', 'flat_load', 's_')) and \
+                not opcode.startswith(('v_cmp', 'v_nop'))
+            first, rest = (body_txt.split(',', 1) + [''])[:2] if has_dest else ('', body_txt)
+
+            def reg_set(txt):
+                out = set()
+                for m in re.finditer(r'\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b', txt):     # (also registers named in an asm comment)
+                    if m.group(5) is not None:
+                        out.add((1000 if m.group(4) == 'a' else 0) + int(m.group(5)))
+                    else:
+                        base = 1000 if m.group(1) == 'a' else 0
+                        out |= set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+                return out
+            written, touched = reg_set(first), reg_set(rest)
+            if not ((touched | written) & d):
                 continue
             if uapp:
                 break            # consumed (or re-loaded) by an asm statement: fine
-            # outside asm: writing the register is a bug too, reading certainly is
-            print('%s: %s  touches the destination of asm load "%s" before its consumer' % (path, u, t))
+            if not (touched & d):
+                break            # only redefined by the compiler (a textually later, exclusive path): that value's life is over
+            print('%s: %s  reads the destination of asm load "%s" before its consumer' % (path, u, t))
             bad += 1
             break
 print('%d asm loads checked, %d violations' % (checked, bad))
