@@ -62,6 +62,7 @@ struct WgradArgs {
     float inv_rs;
     int stagger;
     int zero_slot;      // index of a pixel slot past the tile that the kernel keeps zeroed
+    unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
 };
 
 template <int CINP>
@@ -1594,6 +1595,15 @@ __device__ __forceinline__ int dpre_is_plain(const DpreSeq& q, int tw) {     // 
 __device__ __forceinline__ void dpre_next_plain(DpreSeq& q, int stepb) {
     asm volatile("s_add_i32 %0, %0, 4\n\ts_add_i32 %1, %1, %2" : "+s"(q.c0), "+s"(q.soff) : "s"(stepb) : "scc");
 }
+// the masks by two VALU compares of the lane's group index against the counts (2 VALU + 1 SALU instead of 10 SALU:
+// SALU instructions are free only about 4 to a gap of the MFMA stream)
+__device__ __forceinline__ void dpre_masks_cmp(int nA, int nAF, int kq_lane, unsigned long long& mF, unsigned long long& mB) {
+    unsigned long long t;
+    asm volatile("v_cmp_le_u32 %1, %4, %5\n\t"        // lanes in the next row: kq >= nAF
+                 "v_cmp_le_u32 %2, %3, %5\n\t"        // kq >= nA
+                 "s_andn2_b64 %0, %2, %1"              // fake: nA <= kq < nAF
+                 : "=&s"(mF), "=&s"(mB), "=&s"(t) : "s"(nA), "s"(nAF), "v"(kq_lane) : "scc");
+}
 struct DpreGeo {       // wave-uniform constants of the dpre stream
     int tw, RS, padb, stepb;
 };
@@ -1858,7 +1868,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     constexpr int NQP = 4 / NCH;
     constexpr int QW = (Q + NQP - 1) / NQP;
     constexpr int TPP = CINP / 4, PPP = 256 / TPP;
-    constexpr int U = 16;                    // steps per unrolled window
+    constexpr int U = 14;                    // steps per unrolled window (the host picks TH so that a full unit is a whole number of windows)
     constexpr int NSW = U / 2;               // staging passes per full window: loads in its first half, LDS writes in its second
     constexpr int XSTEP = 4 * PS * 4;        // LDS bytes from one step to the next
     constexpr int LA = 2, RN = 3;            // LDS fragments in flight ahead of the MFMAs / fragment ring
@@ -1961,18 +1971,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     };
 #define SRX_TAKE_OVER_B()                                                                                          \
     do {                                                                                                           \
-        asm volatile("s_waitcnt vmcnt(0) ; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15"                  \
+        asm volatile("s_waitcnt vmcnt(0) ; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13"                          \
                      : "+a"(bnext[0]), "+a"(bnext[1]), "+a"(bnext[2]), "+a"(bnext[3]), "+a"(bnext[4]), "+a"(bnext[5]), \
                        "+a"(bnext[6]), "+a"(bnext[7]), "+a"(bnext[8]), "+a"(bnext[9]), "+a"(bnext[10]),            \
-                       "+a"(bnext[11]), "+a"(bnext[12]), "+a"(bnext[13]), "+a"(bnext[14]), "+a"(bnext[15]));       \
+                       "+a"(bnext[11]), "+a"(bnext[12]), "+a"(bnext[13]));                                         \
         _Pragma("unroll") for (int j = 0; j < U; ++j)                                                              \
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(bcur[j]) : "a"(bnext[j]));   /* (here, not next to the MFMA that uses it) */ \
     } while (0)
-    static_assert(U == 16, "SRX_TAKE_OVER_B names 16 registers");
+    static_assert(U == 14, "SRX_TAKE_OVER_B names 14 registers");
 
     int u = u0;
     int n, h, th;
     tile_of(u, n, h, th);
+    unsigned long long t_loop = 0, t_end = 0, t_full = 0;
+    const unsigned long long t_begin = SRX_STAMP();
     __syncthreads();
     {
         StageSeq qi, qc;
@@ -1993,96 +2005,98 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
         stage_setup(qi, qc, h2, th2, cur_buf ^ 1, has_next);
         const __amdgpu_buffer_rsrc_t xrs = x_rsrc(n2);
         const __amdgpu_buffer_rsrc_t brs = b_rsrc(n, h, th);
+        const __amdgpu_buffer_rsrc_t brs_next = b_rsrc(n2, h2, has_next ? th2 : 0);
 
-        const int nsteps = (th * a.RS + 3) >> 2;
+        // Every window is a FULL window: the steps are padded to a multiple of U (their dpre operand is out of
+        // range -> 0, their x operand whatever finite data lies behind the tile), and the host picks TH so that
+        // a full unit needs no padding.  The step loop then has no branch but its back-edge: each branch -- taken
+        // or not -- costs the MFMA stream 20-35 cycles (shadow3_ubench), six of them per step cost 13 %.
+        const int nsteps = (((th * a.RS + 3) >> 2) + U - 1) / U * U;
         auto read_x = [&](int k, int uu) -> f32x4 { return *(lds_f32x4*)(uintptr_t)(unsigned)(xw[k] + uu * XSTEP); };
         f32x4 ring[RN];
 #pragma unroll
         for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
 
+        const unsigned long long ts_l = SRX_STAMP();
+        __amdgpu_buffer_rsrc_t brs_pf = brs;
         for (int s0 = 0; s0 < nsteps; s0 += U) {
-            // Only FULL windows carry extra work -- the next window's dpre loads (two steps' worth in each of the
-            // first U/2 steps) and NSW staging passes of the next tile: every asm load then has its consumer in
-            // the same straight-line code, and the number of memory operations between the two, which the
-            // s_waitcnt of an LDS write relies on, is known.  ONE loop body for full and partial windows, the
-            // extras behind wave-uniform tests: two bodies make the register allocator give the 144
-            // accumulators two homes and copy them at every window.
-            const bool fullw = (s0 + U <= nsteps);
+            if (s0 + U >= nsteps) {
+                // the unit's last window prefetches the NEXT unit's first dpre window (nothing real when there is none)
+                brs_pf = brs_next;
+                dq.c0 = __builtin_amdgcn_readfirstlane(0);
+                dq.soff = __builtin_amdgcn_readfirstlane(0);
+            }
+            // Extra work of a window: the next window's dpre loads (two steps' worth in each of the first U/2
+            // steps) and NSW staging passes of the next tile (loads in the first half, LDS writes in the second).
+            // Every asm load has its consumer in the same straight-line code, and the number of memory operations
+            // between the two, which the s_waitcnt of an LDS write relies on, is known.
             f32x4 stg[NSW];
 #pragma unroll
             for (int uu = 0; uu < U; ++uu) {
-                if (s0 + uu < nsteps) {
-                    const float b = bcur[uu];
-                    bsum += b;
-                    int nA = 0, nAF = 0;
-                    unsigned long long mA = 0, mAF = 0, mF = 0, mB = 0;
-                    unsigned long long smk = 0, smt = 0;
-                    int sso = 0;
+                const float b = bcur[uu];
+                bsum += b;
+                int nA = 0, nAF = 0;
+                unsigned long long mF = 0, mB = 0;
+                unsigned long long smk = 0, smt = 0;
+                int sso = 0;
 #pragma unroll
-                    for (int k = 0; k < QW; ++k) {
-                        const int idx = (uu * QW + k) % RN;
-                        const int kk = k + LA;
-                        ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
-                        mfma4_wgrad(acc[k], ring[idx], b);
-                        if (k == 0 && uu >= NSW && fullw) {
-                            // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
-                            // count: the two dpre loads of each first-half step after it.
-                            const unsigned long long m = stage_mask_full(qc, SG);
-                            stage_commit_a(2 * (NSW - 1 - (uu - NSW)), qc, m, wl_lane, stg[uu - NSW]);
-                            stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
-                        }
-                        if (uu < U / 2 && fullw) {
-                            // dpre of steps 2uu, 2uu+1 of the next window, at two gaps of the step: masks + load + cursor
+                for (int k = 0; k < QW; ++k) {
+                    const int idx = (uu * QW + k) % RN;
+                    const int kk = k + LA;
+                    ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
+                    mfma4_wgrad(acc[k], ring[idx], b);
+                    if (k == 0 && uu >= NSW) {
+                        // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
+                        // count: the two dpre loads of each first-half step after it.
+                        const unsigned long long m = stage_mask_full(qc, SG);
+                        stage_commit_a(2 * (NSW - 1 - (uu - NSW)), qc, m, wl_lane, stg[uu - NSW]);
+                    }
+                    if (k == 4 && uu >= NSW) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
+                    if (k == 2 && uu == NSW) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);      // (the cursor step of pass NSW-1)
+                    if (uu < NSW) {
+                        // dpre of steps 2uu, 2uu+1 of the next window: eight small pieces over the step's gaps
 #pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                if (k != (half == 0 ? 1 : 6)) continue;
-                                // (the load itself stays outside the branch: an asm-loaded value must not pass a merge point)
-                                const int so = dq.soff;
-                                if (dpre_is_plain(dq, DG.tw)) {
-                                    mF = 0; mB = 0;
-                                    dpre_next_plain(dq, DG.stepb);
-                                } else {
-                                    dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
-                                    mA = low_groups_mask(nA);
-                                    mAF = low_groups_mask(nAF);
-                                    dpre_masks(mA, mAF, mF, mB);
-                                    dpre_next(dq, DG.RS, DG.padb, DG.stepb);
-                                }
-                                bnext[2 * uu + half] = dpre_fire_a(mF, mB, brs, voff_b, voff_bn, so);
-                            }
-                            // one pass of the next tile, in three pieces
-                            if (k == 3) stage_mask_a(qi, SG, smk, smt);
-                            if (k == 4) stage_mask_b(qi, smk, smt, sso);
-                            if (k == QW - 1) {
-                                stg[uu] = stage_fire_a(smk, sso, xrs, voff_lane);
-                                stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);
-                            }
+                        for (int pc = 0; pc < 8; ++pc) {
+                            if (pc + (pc >= 4 ? 1 : 0) != k) continue;      // gaps 0..3 and 5..8
+                            const int p4 = pc % 4;
+                            if (p4 == 0) dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
+                            if (p4 == 1) dpre_masks_cmp(nA, nAF, kq, mF, mB);
+                            if (p4 == 2) bnext[2 * uu + pc / 4] = dpre_fire_a(mF, mB, brs_pf, voff_b, voff_bn, dq.soff);
+                            if (p4 == 3) dpre_next(dq, DG.RS, DG.padb, DG.stepb);
                         }
+                        // one pass of the next tile, in pieces
+                        if (k == 4) { stage_mask_a(qi, SG, smk, smt); stage_mask_b(qi, smk, smt, sso); }
+                        if (k == 6) stg[uu] = stage_fire_a(smk, sso, xrs, voff_lane);
+                        if (k == 2) { if (uu > 0) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }
                     }
                 }
             }
-            if (fullw) SRX_TAKE_OVER_B();
-            // (opaque adds: left to itself the compiler keeps the window offset in an SGPR and adds it to the nine
-            // bases in front of every LDS read -- one VALU instruction per fragment instead of nine per window)
+            SRX_TAKE_OVER_B();
 #pragma unroll
             for (int k = 0; k < QW; ++k) { xw[k] += U * XSTEP; SRX_PIN(xw[k]); }
         }
+        const unsigned long long ts_e = SRX_STAMP();
+        t_loop += ts_e - ts_l;
         {
             // back to step 0, in the other buffer
-            const int nwin = (nsteps + U - 1) / U;
+            const int nwin = nsteps / U;
             const int back = __builtin_amdgcn_readfirstlane((cur_buf ? -buf_bytes : buf_bytes) - nwin * U * XSTEP);
 #pragma unroll
             for (int k = 0; k < QW; ++k) { xw[k] += back; SRX_PIN(xw[k]); }
         }
-        // the next unit's first dpre window travels while the rest of its tile is staged
-        if (has_next) dpre_window_now(b_rsrc(n2, h2, th2));
         stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
         lds_barrier();
-        SRX_TAKE_OVER_B();      // (here, not at the top of the loop: no load may be in flight across the back-edge)
         cur_buf ^= 1;
         u = un_;
+        t_end += SRX_STAMP() - ts_e;
     }
 #undef SRX_TAKE_OVER_B
+#ifdef SRX_TRACE
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_loop; tr[3] = t_end; tr[4] = t_full;
+    }
+#endif
 
     // MFMA results are read by VALU / stores next
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");

@@ -310,6 +310,7 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
     a.stagger = stagger_sleeps(p);
     a.zero_slot = (p.TH + d->KH - 1) * p.RS + (d->KW - 1);      // first slot after the largest tile
+    { const char* tp = getenv("SRX_TRACE_PTR"); a.trace = tp ? (unsigned long long*)strtoull(tp, nullptr, 0) : nullptr; }   // diagnostic builds only
     const size_t wg_lds = p.lds_bytes + (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
@@ -329,9 +330,25 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     int wgrid = p.grid;
     bool wdone = false;
     if (use_wpipe && lin_ok && d->Cin == p.cinp && p.RS >= wppp && 2 * lin_lds <= 160 * 1024) {
-        wgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
-        wdone = launch_wgrad_pipe(k, a, wgrid, 2 * lin_lds, s, &err);
-        if (!wdone) wgrid = p.grid;
+        // Its step loop runs whole windows of 14 steps (4 positions each), padding a unit's last window with
+        // zero-operand steps: pick the tile height that wastes the fewest (41-wide rows: 4 rows = 168 positions =
+        // 3 windows exactly), and make sure the padded walk stays inside the tile buffer.
+        const int kWin = 14 * 4;
+        int best_th = 0;
+        double best_waste = 1e9;
+        for (int th = p.TH; th >= 1; --th) {
+            const long pos = (long)th * p.RS, padded = (pos + kWin - 1) / kWin * kWin;
+            const double waste = (double)(padded - pos) / (double)pos;
+            const bool fits = padded + 2L * p.RS + 6 <= (long)a.zero_slot + 4;
+            if (fits && waste < best_waste - 1e-9) { best_waste = waste; best_th = th; }
+        }
+        if (best_th > 0 && best_waste <= 0.10) {
+            WgradArgs ap = a;
+            ap.TH = best_th;
+            wgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+            wdone = launch_wgrad_pipe(k, ap, wgrid, 2 * lin_lds, s, &err);
+            if (!wdone) wgrid = p.grid;
+        }
     }
     if (wdone) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const float* gsrc, float
                 if (KIND == 10) asm volatile("s_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen\n\ts_mov_b64 exec, -1" : "=v"(ld) : "v"(voff), "s"(xr), "s"(soff), "s"(m0) : "memory");
                 if (KIND == 11) asm volatile("s_waitcnt lgkmcnt(0)");
                 if (KIND == 12) asm volatile("s_waitcnt vmcnt(0)");
+                if (KIND == 13) asm volatile("s_branch 1f\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n1:");            // taken branch over 4 instructions
+                if (KIND == 14) asm volatile("s_cmp_eq_u32 %0, %0\n\ts_cbranch_scc0 1f\n\ts_nop 0\n1:" : : "s"(s1) : "scc");   // not-taken conditional branch
+                if (KIND == 15) asm volatile("s_cmp_eq_u32 %0, %0\n\ts_cbranch_scc1 1f\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n1:" : : "s"(s1) : "scc");   // taken conditional branch over 20 instructions
             }
             if (KIND == 8 || KIND == 9 || KIND == 10) soff = (soff + 4096) & ((1 << 23) - 1);
         }
@@ -107,5 +110,6 @@ int main() {
     R(1, "s_add_u32") R(2, "s_cmp+s_cselect") R(3, "s_mov exec x2") R(4, "s_mul_i32")
     R(5, "ds_read_b32") R(6, "ds_read_b128") R(7, "ds_write_b128") R(8, "buffer_load_x4 soffset")
     R(9, "buffer_store_x4 soffset") R(10, "exec-masked buffer_load") R(11, "s_waitcnt lgkmcnt(0)") R(12, "s_waitcnt vmcnt(0)")
+    R(13, "taken s_branch (+4)") R(14, "not-taken s_cbranch") R(15, "taken s_cbranch (+20)")
     return 0;
 }
