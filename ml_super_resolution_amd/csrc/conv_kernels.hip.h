@@ -799,9 +799,6 @@ __device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const
     stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
 }
 
-#ifndef SRX_WG_NB
-#define SRX_WG_NB 6
-#endif
 // a whole tile with NB loads in flight (kernels that stage between their MFMA phases)
 template <int CINP, int NB>
 __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
@@ -1584,17 +1581,6 @@ __device__ __forceinline__ void dpre_next(DpreSeq& q, int RS, int padb, int step
                  "s_cselect_b32 %2, %4, 0\n\ts_cselect_b32 %3, %5, 0\n\ts_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %3"
                  : "+s"(q.c0), "+s"(q.soff), "=&s"(t), "=&s"(t2) : "s"(RS), "s"(padb), "s"(stepb) : "scc");
 }
-// SALU instructions are not free in bulk either (about 4 per gap of the MFMA stream are): most steps lie wholly
-// inside one tile row, where the masks are empty and the cursor simply moves on -- those take a short path
-// behind one wave-uniform branch.
-__device__ __forceinline__ int dpre_is_plain(const DpreSeq& q, int tw) {     // all four positions real and in this row
-    int t;
-    asm volatile("s_add_i32 %0, %1, 4\n\ts_cmp_le_i32 %0, %2\n\ts_cselect_b32 %0, 1, 0" : "=&s"(t) : "s"(q.c0), "s"(tw) : "scc");
-    return t;
-}
-__device__ __forceinline__ void dpre_next_plain(DpreSeq& q, int stepb) {
-    asm volatile("s_add_i32 %0, %0, 4\n\ts_add_i32 %1, %1, %2" : "+s"(q.c0), "+s"(q.soff) : "s"(stepb) : "scc");
-}
 // the masks by two VALU compares of the lane's group index against the counts (2 VALU + 1 SALU instead of 10 SALU:
 // SALU instructions are free only about 4 to a gap of the MFMA stream)
 __device__ __forceinline__ void dpre_masks_cmp(int nA, int nAF, int kq_lane, unsigned long long& mF, unsigned long long& mB) {
@@ -1633,10 +1619,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     constexpr int U = 12;                    // steps per unrolled window (U*QW is a multiple of 3, U of 4)
     constexpr int XSTEP = 4 * PS * 4;        // LDS bytes from one step to the next
     constexpr int PF = 3;                    // dpre prefetch distance in steps
-#ifndef SRX_WG_LA
-#define SRX_WG_LA 2
-#endif
-    constexpr int LA = (QW >= 2) ? ((U * QW) % (SRX_WG_LA + 1) == 0 ? SRX_WG_LA : 2) : 1;    // LDS fragments in flight ahead of the MFMAs
+    constexpr int LA = (QW >= 2) ? 2 : 1;    // LDS fragments in flight ahead of the MFMAs (3 or 5 measured no faster)
     constexpr int RN = LA + 1;               // fragment ring
     static_assert((U * QW) % RN == 0 && U % 4 == 0, "window must keep the register rings in phase");
     const int tid = threadIdx.x;
@@ -1721,7 +1704,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
             qc.thr = 0;
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
-            stage_tile_scalar<CINP, SRX_WG_NB>(qi, qc, SG, xrs, voff_lane, wl_lane);
+            stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
         } else {
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, -a.pad_l, a.RS, a.inv_rs,
                              (th + KH - 1) * a.RS + (KW - 1), tid);
