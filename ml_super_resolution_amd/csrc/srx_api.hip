@@ -60,7 +60,9 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     if (RS < OW + KW - 1 - (KW - 1 - pad_l)) RS = OW + pad_l;
     int TW = OW, NTX = 1;
     long th_max = ((long)max_slots - (KW - 1)) / RS - (KH - 1);
-    if (th_max < 1) {
+    static int min_full_th = -1;
+    if (min_full_th < 0) { const char* e = getenv("SRX_MIN_FULL_TH"); min_full_th = e ? atoi(e) : 3; }   // full-width tiles of 1-2 rows re-stage 3 input rows per output row: measured slower than column tiles
+    if (th_max < min_full_th) {
         // column tiling: each tile carries its own halo columns; narrow the tile until it fits
         for (TW = 32; TW >= 8; TW >>= 1) {
             RS = TW + KW - 1;
