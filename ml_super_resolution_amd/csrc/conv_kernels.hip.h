@@ -832,8 +832,8 @@ template <int MAXG, int AUX>
 struct PipePend {      // a finished group waiting for its epilogue
     f32x4 acc[MAXG];
     f32x4 aux[AUX ? MAXG : 1];
-    float* ybase;      // wave-uniform: y of (image, first row of the unit)
-    int m_first, gs, npx;
+    __amdgpu_buffer_rsrc_t yrs;   // wave-uniform: the unit's output pixels
+    int m_first, gs;
 };
 struct PipeEpi {
     int lo, lo2;       // wave-uniform clamps
@@ -857,12 +857,12 @@ __device__ __forceinline__ f32x4 clamp_lo4(f32x4 v, int lo) {
     }
     return v;
 }
-// Buffer resource of sub-tile m of a unit: base = its first pixel, num_records = the bytes of its pixels that
-// exist (npx - 16m of them, 16 at most matter) -> the range check drops the tail of a short last sub-tile.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t subtile_rsrc(const float* unit_base, int m, int npx, bool live, int cout4) {
-    const int rem = npx - 16 * m;
-    const int nrec = (live && rem > 0) ? rem * cout4 : 0;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(unit_base) + (size_t)(4 * m) * cout4, 0, nrec, 0x00020000);
+// Output / aux addressing of sub-tile m of a unit: ONE buffer resource per unit (base = the unit's first pixel,
+// num_records = the bytes of its pixels), the sub-tile as the scalar offset (it takes part in the range check, so
+// the pixels past the end of a short last sub-tile are dropped), a constant lane offset.  Dummy sub-tiles get an
+// out-of-range scalar offset.
+__device__ __forceinline__ int subtile_soffset(int m, bool live, int cout4) {
+    return live ? m * 16 * cout4 : 0x7ff00000;
 }
 // Epilogue of ONE parked sub-tile.  The host sends only these forms to the pipelined kernel:
 //   no aux:  y = max_int(acc, lo)                    lo = 0 (ReLU) or INT_MIN (no activation)
@@ -883,8 +883,8 @@ __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd,
     } else {
         v = clamp_lo4(v, ep.lo);
     }
-    const __amdgpu_buffer_rsrc_t r = subtile_rsrc(pd.ybase, pd.m_first + i * NPART, pd.npx, i < pd.gs, ep.cout4);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, vst, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), pd.yrs, vst,
+                                           subtile_soffset(pd.m_first + i * NPART, i < pd.gs, ep.cout4), 0);
 }
 
 // One k-step (4 input channels of one tap) for G accumulators: G MFMAs, weight from an AGPR.
@@ -913,9 +913,7 @@ __device__ __forceinline__ void mfma_sub_a_first(f32x4 (&c)[3], f32x4 bias4, flo
 }
 
 struct PipeUnit {      // wave-uniform description of the running unit
-    int npx;
-    float* ybase;
-    const float* auxbase;
+    __amdgpu_buffer_rsrc_t yrs, auxrs;   // its output pixels / the aux operand's
 };
 
 // One group of G (<= MAXG) sub-tiles m_first, m_first+NPART, ...  On entry `cur` holds the LDS fragments of
@@ -952,8 +950,8 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     if (AUX) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const __amdgpu_buffer_rsrc_t r = subtile_rsrc(un.auxbase, m_first + i * NPART, un.npx, i < gs, ep.cout4);
-            aux[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vst, 0, 0));
+            aux[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                un.auxrs, vst, subtile_soffset(m_first + i * NPART, i < gs, ep.cout4), 0));
         }
     }
     int lan[MAXG];
@@ -1029,7 +1027,7 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
         pd.acc[i] = (i < G) ? acc[i < G ? i : 0] : bias4;
         if (AUX) pd.aux[i] = (i < G) ? aux[i < G ? i : 0] : bias4;
     }
-    pd.ybase = un.ybase; pd.m_first = m_first; pd.gs = gs; pd.npx = un.npx;
+    pd.yrs = un.yrs; pd.m_first = m_first; pd.gs = gs;
     tt[1] += SRX_STAMP() - ts_m;
 }
 
@@ -1171,7 +1169,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MAXG; ++i) pd.aux[i] = bias4;
     }
-    pd.ybase = a.y; pd.m_first = 0; pd.gs = 0; pd.npx = 0;
+    pd.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000); pd.m_first = 0; pd.gs = 0;
 
     int cur_buf = 0;
     int u = u0;
@@ -1188,12 +1186,13 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
             const_cast<float*>(a.x) + ((size_t)n2 * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
 
         PipeUnit un;
-        un.npx = th * a.OW;
+        const int npx = th * a.OW;
         const size_t unit_off = ((size_t)n * a.OH + h) * a.OW * a.Cout;
-        un.ybase = a.y + unit_off;
-        un.auxbase = AUX ? auxp + unit_off : a.x;
+        un.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_off, 0, npx * ep.cout4, 0x00020000);
+        un.auxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AUX ? auxp + unit_off : a.x), 0,
+                                                     AUX ? npx * ep.cout4 : 0, 0x00020000);
 
-        const int n_sub = (un.npx + 15) >> 4;
+        const int n_sub = (npx + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;
         if (cnt > 0) {
             const int ng = (cnt + MAXG - 1) / MAXG;
