@@ -1840,6 +1840,14 @@ __device__ __forceinline__ float dpre_fire_a(unsigned long long mF, unsigned lon
     return b;
 }
 
+// dpre load with a ready lane offset (wgrad_pipe_kernel looks it up in an LDS table keyed by the column of the step's
+// first position)
+__device__ __forceinline__ float dpre_fire_tab(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    float b;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&a"(b) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return b;
+}
+
 template <int KH, int KW, int CINP, int NCH>
 __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1887,6 +1895,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < 2 * buf_bytes / 16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
     }
+    __syncthreads();
+    // dpre lane-offset table, keyed by the column c0 of a step's first position, in the pad words of the first RS
+    // slots of buffer 0 (staging writes only the data floats): entry (c0, kq) = the offset of lane group kq's position
+    // c0 + kq -- in this row (biased by RS-OW pixels, see below), fake (out of range), or in the next row
+    for (int i = tid; i < a.RS * 4; i += 256) {
+        const int c0 = i >> 2, g = i & 3, col = c0 + g;
+        const int v = col < a.OW ? (g * a.Cout + (a.RS - a.OW) * a.Cout) * 4 : (col < a.RS ? 0x7ff00000 : g * a.Cout * 4);
+        *reinterpret_cast<int*>(ldsb + (c0 * PS + CINP + g) * 4) = v;
+    }
     const int voff_lane = tid * 16;
     const int wl_lane = (sp * PS + 4 * c4) * 4;
     StageGeo SG;
@@ -1903,6 +1920,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     DG.stepb = __builtin_amdgcn_readfirstlane(16 * a.Cout);
     const int voff_bn = (kq * a.Cout + co_c) * 4;
     const int voff_b = voff_bn + (a.RS - a.OW) * a.Cout * 4;
+    const int tbl_lane = lds_base + (CINP + kq) * 4;      // this lane's word of a table entry
+    const int co4 = co_c * 4;
 
     f32x4 acc[QW][4];
 #pragma unroll
@@ -2017,8 +2036,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
             for (int uu = 0; uu < U; ++uu) {
                 const float b = bcur[uu];
                 bsum += b;
-                int nA = 0, nAF = 0;
-                unsigned long long mF = 0, mB = 0;
+                int tv = 0;
                 unsigned long long smk = 0, smt = 0;
                 int sso = 0;
 #pragma unroll
@@ -2027,6 +2045,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
                     const int kk = k + LA;
                     ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
                     mfma4_wgrad(acc[k], ring[idx], b);
+#ifndef SRX_EXP_W_NOSTAGE
                     if (k == 0 && uu >= NSW) {
                         // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
                         // count: the two dpre loads of each first-half step after it.
@@ -2035,21 +2054,23 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
                     }
                     if (k == 4 && uu >= NSW) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
                     if (k == 2 && uu == NSW) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);      // (the cursor step of pass NSW-1)
+#endif
                     if (uu < NSW) {
                         // dpre of steps 2uu, 2uu+1 of the next window: eight small pieces over the step's gaps
 #pragma unroll
                         for (int pc = 0; pc < 8; ++pc) {
                             if (pc + (pc >= 4 ? 1 : 0) != k) continue;      // gaps 0..3 and 5..8
                             const int p4 = pc % 4;
-                            if (p4 == 0) dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
-                            if (p4 == 1) dpre_masks_cmp(nA, nAF, kq, mF, mB);
-                            if (p4 == 2) bnext[2 * uu + pc / 4] = dpre_fire_a(mF, mB, brs_pf, voff_b, voff_bn, dq.soff);
+                            if (p4 == 0) tv = *(__attribute__((address_space(3))) const int*)(uintptr_t)(unsigned)(tbl_lane + dq.c0 * (PS * 4));
+                            if (p4 == 2) bnext[2 * uu + pc / 4] = dpre_fire_tab(brs_pf, tv + co4, dq.soff);
                             if (p4 == 3) dpre_next(dq, DG.RS, DG.padb, DG.stepb);
                         }
                         // one pass of the next tile, in pieces
+#ifndef SRX_EXP_W_NOSTAGE
                         if (k == 4) { stage_mask_a(qi, SG, smk, smt); stage_mask_b(qi, smk, smt, sso); }
                         if (k == 6) stg[uu] = stage_fire_a(smk, sso, xrs, voff_lane);
                         if (k == 2) { if (uu > 0) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }
+#endif
                     }
                 }
             }
