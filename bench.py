@@ -168,7 +168,7 @@ def main():
                          'frac': round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          # HBM bytes per launch from the PMC passes committed under profiles/ (2*FETCH_SIZE +
                          # WRITE_SIZE, gfx950 correction); algorithmic bytes are 220.3e6 (input + output once)
-                         'traffic': 2.219e8, 'traffic_source': 'profiles/r01_prof_conv_hbm_counters.csv',
+                         'traffic': 2.225e8, 'traffic_source': 'profiles/r01_prof_conv_hbm_counters.csv',
                          'launch_ms': round(mid_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

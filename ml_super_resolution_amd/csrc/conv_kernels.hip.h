@@ -1580,15 +1580,6 @@ __device__ __forceinline__ void dpre_next(DpreSeq& q, int RS, int padb, int step
                  "s_cselect_b32 %2, %4, 0\n\ts_cselect_b32 %3, %5, 0\n\ts_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %3"
                  : "+s"(q.c0), "+s"(q.soff), "=&s"(t), "=&s"(t2) : "s"(RS), "s"(padb), "s"(stepb) : "scc");
 }
-// the masks by two VALU compares of the lane's group index against the counts (2 VALU + 1 SALU instead of 10 SALU:
-// SALU instructions are free only about 4 to a gap of the MFMA stream)
-__device__ __forceinline__ void dpre_masks_cmp(int nA, int nAF, int kq_lane, unsigned long long& mF, unsigned long long& mB) {
-    unsigned long long t;
-    asm volatile("v_cmp_le_u32 %1, %4, %5\n\t"        // lanes in the next row: kq >= nAF
-                 "v_cmp_le_u32 %2, %3, %5\n\t"        // kq >= nA
-                 "s_andn2_b64 %0, %2, %1"              // fake: nA <= kq < nAF
-                 : "=&s"(mF), "=&s"(mB), "=&s"(t) : "s"(nA), "s"(nAF), "v"(kq_lane) : "scc");
-}
 struct DpreGeo {       // wave-uniform constants of the dpre stream
     int tw, RS, padb, stepb;
 };
@@ -1828,18 +1819,6 @@ __device__ __forceinline__ void stage_commit_a(int pend, const StageSeq& q, unsi
     else if (pend == 2) SRX_COMMIT_ASM_A(2);
     else SRX_COMMIT_ASM_A(0);
 }
-__device__ __forceinline__ float dpre_fire_a(unsigned long long mF, unsigned long long mB, __amdgpu_buffer_rsrc_t rsrc,
-                                             int voff, int voff_next_row, int soff) {
-    int v;
-    float b;
-    asm volatile("v_cndmask_b32 %1, %2, %3, %4\n\t"
-                 "v_cndmask_b32 %1, %1, %5, %6\n\t"
-                 "buffer_load_dword %0, %1, %7, %8 offen"
-                 : "=&a"(b), "=&v"(v) : "v"(voff), "v"(voff_next_row), "s"(mB), "v"(kOobOffset), "s"(mF), "s"(rsrc), "s"(soff)
-                 : "memory");
-    return b;
-}
-
 // dpre load with a ready lane offset (wgrad_pipe_kernel looks it up in an LDS table keyed by the column of the step's
 // first position)
 __device__ __forceinline__ float dpre_fire_tab(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
@@ -2045,7 +2024,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
                     const int kk = k + LA;
                     ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
                     mfma4_wgrad(acc[k], ring[idx], b);
-#ifndef SRX_EXP_W_NOSTAGE
                     if (k == 0 && uu >= NSW) {
                         // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
                         // count: the two dpre loads of each first-half step after it.
@@ -2054,7 +2032,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
                     }
                     if (k == 4 && uu >= NSW) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
                     if (k == 2 && uu == NSW) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);      // (the cursor step of pass NSW-1)
-#endif
                     if (uu < NSW) {
                         // dpre of steps 2uu, 2uu+1 of the next window: eight small pieces over the step's gaps
 #pragma unroll
@@ -2066,11 +2043,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
                             if (p4 == 3) dpre_next(dq, DG.RS, DG.padb, DG.stepb);
                         }
                         // one pass of the next tile, in pieces
-#ifndef SRX_EXP_W_NOSTAGE
                         if (k == 4) { stage_mask_a(qi, SG, smk, smt); stage_mask_b(qi, smk, smt, sso); }
                         if (k == 6) stg[uu] = stage_fire_a(smk, sso, xrs, voff_lane);
                         if (k == 2) { if (uu > 0) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }
-#endif
                     }
                 }
             }
