@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
         stage_setup(qi, qc, h, th, 0, true);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
-        while (qi.left > 0) stage_pass_now<CINP>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);   // (6 loads in flight: the first tile is the only one whose latency is exposed)
     }
     lds_barrier();
     const unsigned long long t_first = SRX_STAMP();
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
         }
         // drain: whatever part of the next tile the groups did not cover
         const unsigned long long ts_d = SRX_STAMP();
-        while (qi.left > 0) stage_pass_now<CINP>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
         lds_barrier();
         tt[3] += SRX_STAMP() - ts_d;
         cur_buf ^= 1;
