@@ -1054,18 +1054,10 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
 #ifdef SRX_TRACE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
+    // the weight loads are issued first and collected last (after the first tile is staged): their latency overlaps
+    // the LDS set-up and the first tile's loads
     float wr[TAPS * KSPT];
-    {
-        load_stationary_weights<TAPS, CINP, WT>(wr, a, cout0, li, kq);
-        // all loads are in flight; now move the weights into the accumulation-register file for good: they
-        // are defined as "a" values here and only ever consumed by "a" operands of the MFMA statements.
-        // (One asm per weight right after its own load would serialise 144 global-load round trips.)
-#pragma unroll
-        for (int i = 0; i < TAPS * KSPT; ++i) {
-            float t = wr[i];
-            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(wr[i]) : "v"(t));
-        }
-    }
+    load_stationary_weights<TAPS, CINP, WT>(wr, a, cout0, li, kq);
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll
@@ -1160,6 +1152,14 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
         stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);   // (6 loads in flight: the first tile is the only one whose latency is exposed)
     }
     lds_barrier();
+    // now move the weights into the accumulation-register file for good: they are defined as "a" values here and
+    // only ever consumed by "a" operands of the MFMA statements.  (One asm per weight right after its own load
+    // would serialise 144 global-load round trips.)
+#pragma unroll
+    for (int i = 0; i < TAPS * KSPT; ++i) {
+        float t = wr[i];
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(wr[i]) : "v"(t));
+    }
     const unsigned long long t_first = SRX_STAMP();
 
     PipePend<MAXG, AUX> pd;
