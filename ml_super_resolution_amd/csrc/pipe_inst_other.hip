@@ -6,8 +6,6 @@ bool launch_pipe_other(const ConvKey& k, const ConvArgs& a, int grid, size_t lds
     SRX_PIPE_CASE_DGRAD(3, 3, 32, 4)
     SRX_PIPE_CASE_FWD(3, 3, 32, 2)
     SRX_PIPE_CASE_DGRAD(3, 3, 32, 2)
-    SRX_PIPE_CASE_FWD(3, 3, 32, 1)
-    SRX_PIPE_CASE_DGRAD(3, 3, 32, 1)
     return false;
 }
 }  // namespace srx
