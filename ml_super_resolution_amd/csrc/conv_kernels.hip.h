@@ -698,6 +698,7 @@ struct StageGeo {      // wave-uniform constants of the staging sequence
     int JP1;           // passes per tile row, minus 1
     int rowfix_g, rowfix_l;  // extra bytes (beyond the constant pass step) when the next pass starts a new row: image, LDS
     unsigned long long m_first, m_last;   // EXEC masks of a row's first / last pass (pad columns / row end)
+    unsigned long long m_row;             // column-strip tiles only: lanes of a row's last pass that lie inside the tile row
 };
 // The scalar offset is UNSIGNED to the hardware (measured: a negative one puts the whole pass out of range),
 // so the buffer resource starts pad_l pixels before the image (those bytes are never touched: the lanes
@@ -756,6 +757,51 @@ __device__ __forceinline__ f32x4 stage_fire(unsigned long long m, int so, __amdg
                  : "=&v"(v) : "v"(voff_lane), "s"(rsrc), "s"(so), "s"(m) : "memory");
     return v;
 }
+// ---- column-strip tiles ("Z" variants).  A strip carries real halo columns on both sides, except where it touches
+// the image edge: there the halo slots must read as zero, and since a buffer holds strips of different columns
+// in turn they cannot be zeroed once.  So a pass issues TWO loads into the same register: the valid lanes from the
+// image, the edge-halo lanes with an out-of-range scalar offset (they return 0); one LDS write covers both.
+// m_first / m_last are then the VALID lanes of a row's first / last pass for the strip being staged (set per
+// tile), m_row the lanes inside the tile row.
+__device__ __forceinline__ void stage_mask_az(const StageSeq& q, const StageGeo& G, unsigned long long& m, unsigned long long& t,
+                                              unsigned long long& r) {
+    asm volatile("s_cmp_eq_u32 %3, 0\n\t"
+                 "s_cselect_b64 %0, %5, -1\n\t"
+                 "s_cmp_eq_u32 %3, %4\n\t"
+                 "s_cselect_b64 %1, %6, -1\n\t"
+                 "s_cselect_b64 %2, %7, -1"
+                 : "=&s"(m), "=&s"(t), "=&s"(r) : "s"(q.j), "s"(G.JP1), "s"(G.m_first), "s"(G.m_last), "s"(G.m_row) : "scc");
+}
+// after this: r = lanes the pass writes to LDS (none once the tile is complete), m = those of them loaded from the image
+__device__ __forceinline__ void stage_mask_bz(const StageSeq& q, unsigned long long& m, unsigned long long t, unsigned long long& r,
+                                              int& so) {
+    asm volatile("s_and_b64 %0, %0, %3\n\t"
+                 "s_cmp_gt_i32 %4, 0\n\t"
+                 "s_cselect_b64 %1, %1, 0\n\t"
+                 "s_and_b64 %0, %0, %1\n\t"
+                 "s_cmp_gt_i32 %4, %5\n\t"
+                 "s_cselect_b32 %2, 0x7ff00000, %6"
+                 : "+s"(m), "+s"(r), "=&s"(so) : "s"(t), "s"(q.left), "s"(q.thr), "s"(q.off) : "scc");
+}
+__device__ __forceinline__ f32x4 stage_fire_z(unsigned long long m, unsigned long long r, int so, __amdgpu_buffer_rsrc_t rsrc,
+                                              int voff_lane) {
+    f32x4 v;
+    unsigned long long z;
+    const int oob = 0x7ff00000;
+    asm volatile("s_andn2_b64 %1, %6, %5\n\t"
+                 "s_mov_b64 exec, %5\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                 "s_mov_b64 exec, %1\n\tbuffer_load_dwordx4 %0, %2, %3, %7 offen\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&v"(v), "=&s"(z) : "v"(voff_lane), "s"(rsrc), "s"(so), "s"(m), "s"(r), "s"(oob) : "memory", "scc");
+    return v;
+}
+// the lanes a cursor's pass writes to LDS, from the commit cursor alone
+__device__ __forceinline__ unsigned long long stage_mask_row(const StageSeq& q, const StageGeo& G) {
+    unsigned long long r;
+    asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b64 %0, %3, -1\n\ts_cmp_gt_i32 %4, 0\n\ts_cselect_b64 %0, %0, 0"
+                 : "=&s"(r) : "s"(q.j), "s"(G.JP1), "s"(G.m_row), "s"(q.left) : "scc");
+    return r;
+}
 // (4) advance a cursor by one pass
 template <int STEP>
 __device__ __forceinline__ void stage_next(StageSeq& q, int JP1, int rowfix) {
@@ -777,7 +823,12 @@ __device__ __forceinline__ void stage_next(StageSeq& q, int JP1, int rowfix) {
 __device__ __forceinline__ void stage_commit(int pend, const StageSeq& q, unsigned long long m, int wl_lane, const f32x4 v) {
     int addr;
     // (pend is a constant after unrolling: the chain folds to one statement)
-    if (pend >= 5) SRX_COMMIT_ASM(5);
+    if (pend >= 14) SRX_COMMIT_ASM(14);
+    else if (pend >= 12) SRX_COMMIT_ASM(12);
+    else if (pend >= 10) SRX_COMMIT_ASM(10);
+    else if (pend >= 8) SRX_COMMIT_ASM(8);
+    else if (pend >= 6) SRX_COMMIT_ASM(6);
+    else if (pend == 5) SRX_COMMIT_ASM(5);
     else if (pend == 4) SRX_COMMIT_ASM(4);
     else if (pend == 3) SRX_COMMIT_ASM(3);
     else if (pend == 2) SRX_COMMIT_ASM(2);
@@ -800,7 +851,7 @@ __device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const
 }
 
 // a whole tile with NB loads in flight (kernels that stage between their MFMA phases)
-template <int CINP, int NB>
+template <int CINP, int NB, bool Z = false>
 __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
                                                   int voff_lane, int wl_lane) {
     constexpr int PPP = 256 / (CINP / 4);
@@ -811,14 +862,21 @@ __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, co
         for (int i = 0; i < NB; ++i) {
             unsigned long long t;
             int so;
-            stage_mask_a(qi, G, mk[i], t);
-            stage_mask_b(qi, mk[i], t, so);
-            v[i] = stage_fire(mk[i], so, rsrc, voff_lane);
+            if constexpr (Z) {
+                unsigned long long m;
+                stage_mask_az(qi, G, m, t, mk[i]);
+                stage_mask_bz(qi, m, t, mk[i], so);
+                v[i] = stage_fire_z(m, mk[i], so, rsrc, voff_lane);
+            } else {
+                stage_mask_a(qi, G, mk[i], t);
+                stage_mask_b(qi, mk[i], t, so);
+                v[i] = stage_fire(mk[i], so, rsrc, voff_lane);
+            }
             stage_next<PPP * CINP * 4>(qi, G.JP1, G.rowfix_g);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            stage_commit(NB - 1 - i, qc, mk[i], wl_lane, v[i]);
+            stage_commit((Z ? 2 : 1) * (NB - 1 - i), qc, mk[i], wl_lane, v[i]);
             stage_next<PPP * Lds<CINP>::PS * 4>(qc, G.JP1, G.rowfix_l);
         }
     }
@@ -838,6 +896,7 @@ struct PipePend {      // a finished group waiting for its epilogue
 struct PipeEpi {
     int lo, lo2;       // wave-uniform clamps
     int cout4;         // Cout * 4
+    int sh, rowb;      // column strips: log2(sub-tiles per strip row), bytes of one output row
 };
 // AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add
 template <int AUX>
@@ -846,6 +905,8 @@ __device__ __forceinline__ PipeEpi pipe_epi_setup(const ConvArgs& a) {
     e.lo = (a.act == ACT_RELU) ? 0 : (int)0x80000000;
     e.lo2 = (AUX == 2 && a.post_relu) ? 0 : (int)0x80000000;
     e.cout4 = a.Cout * 4;
+    e.sh = (a.TW >= 32) ? 1 : 0;
+    e.rowb = a.OW * a.Cout * 4;
     return e;
 }
 __device__ __forceinline__ f32x4 clamp_lo4(f32x4 v, int lo) {
@@ -861,14 +922,22 @@ __device__ __forceinline__ f32x4 clamp_lo4(f32x4 v, int lo) {
 // num_records = the bytes of its pixels), the sub-tile as the scalar offset (it takes part in the range check, so
 // the pixels past the end of a short last sub-tile are dropped), a constant lane offset.  Dummy sub-tiles get an
 // out-of-range scalar offset.
-__device__ __forceinline__ int subtile_soffset(int m, bool live, int cout4) {
-    return live ? m * 16 * cout4 : 0x7ff00000;
+// (Column strips, Z: the strip is 16 << sh pixels wide, so sub-tile m is the 16 pixels from column 16 (m mod 2^sh) of
+// strip row m >> sh; the unit's resource starts at the strip's first pixel and rows are a whole image row apart.)
+template <bool Z>
+__device__ __forceinline__ int subtile_soffset(int m, bool live, const PipeEpi& ep) {
+    if constexpr (Z) {
+        const int r = m >> ep.sh, c = m - (r << ep.sh);
+        return live ? r * ep.rowb + c * 16 * ep.cout4 : 0x7ff00000;
+    } else {
+        return live ? m * 16 * ep.cout4 : 0x7ff00000;
+    }
 }
 // Epilogue of ONE parked sub-tile.  The host sends only these forms to the pipelined kernel:
 //   no aux:  y = max_int(acc, lo)                    lo = 0 (ReLU) or INT_MIN (no activation)
 //   mask:    y = (mask > 0) ? acc : 0                ReluGrad on the saved activation (dgrad)
 //   skip:    y = max_int(max_int(acc, lo) + skip, lo2)      residual add, optional ReLU after it
-template <int MAXG, int AUX, int NPART>
+template <int MAXG, int AUX, int NPART, bool Z = false>
 __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd, int i, const PipeEpi& ep, int vst) {
     f32x4 v = pd.acc[i];
     if (AUX == 1) {
@@ -884,7 +953,7 @@ __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd,
         v = clamp_lo4(v, ep.lo);
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), pd.yrs, vst,
-                                           subtile_soffset(pd.m_first + i * NPART, i < pd.gs, ep.cout4), 0);
+                                           subtile_soffset<Z>(pd.m_first + i * NPART, i < pd.gs, ep), 0);
 }
 
 // One k-step (4 input channels of one tap) for G accumulators: G MFMAs, weight from an AGPR.
@@ -928,7 +997,7 @@ struct PipeUnit {      // wave-uniform description of the running unit
 //                  blocks E0.., gap 1: the previous group's epilogue, one sub-tile per block;
 //                  block A0, gap 3: the next group's LDS addresses (table reads).
 // No branches in here: every taken branch stalls the stream for an instruction refetch.
-template <int KH, int KW, int CINP, int G, int MAXG, int AUX, int NPART>
+template <int KH, int KW, int CINP, int G, int MAXG, int AUX, int NPART, bool Z = false>
 __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&wr)[KH * KW * (CINP / 4)],
                                                 const f32x4 bias4, int row_stride_b, StageSeq& qi, StageSeq& qc,
                                                 const StageGeo& SG, __amdgpu_buffer_rsrc_t xrs, int voff_lane, int wl_lane,
@@ -938,7 +1007,8 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = CINP / 16;
     constexpr int NBLK = KH * KW * NG;
-    constexpr int NST = (NBLK / 2 < 6) ? NBLK / 2 : 6;   // staging passes threaded through this group
+    constexpr int NSTW = Z ? 8 : 6;                       // (a strip tile has 6 (TH + 2) / TH passes per group of 4 sub-tiles)
+    constexpr int NST = (NBLK / 2 < NSTW) ? NBLK / 2 : NSTW;   // staging passes threaded through this group
     constexpr int E0 = NST;                               // first epilogue block
     constexpr int A0 = NST + MAXG;                        // address block
     constexpr int TSTEP = 16 * PS * 4 * NPART;            // table bytes from one sub-tile of the wave to the next
@@ -951,14 +1021,14 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             aux[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                un.auxrs, vst, subtile_soffset(m_first + i * NPART, i < gs, ep.cout4), 0));
+                un.auxrs, vst, subtile_soffset<Z>(m_first + i * NPART, i < gs, ep), 0));
         }
     }
     int lan[MAXG];
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) lan[i] = 0;
     f32x4 stg[NST];
-    unsigned long long mk[NST], mt;
+    unsigned long long mk[Z ? 1 : NST], mt, mv = 0, mr = 0;   // (strips: the write mask comes from the commit cursor)
     int so;
     f32x4 nxt[MAXG];
     f32x4 cg[MAXG];
@@ -986,20 +1056,33 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
             // ---- gap ks
             if (ks == 0) {
                 frag(0);
-                if (t < NST) stage_mask_a(qi, SG, mk[t], mt);
+                if (t < NST) {
+                    if constexpr (Z) stage_mask_az(qi, SG, mv, mt, mr);
+                    else stage_mask_a(qi, SG, mk[t], mt);
+                }
             } else if (ks == 1) {
                 frag(1);
-                if (t < NST) stage_mask_b(qi, mk[t], mt, so);
-                if (t >= NBLK / 2 && t < NBLK / 2 + NST)
-                    stage_commit(NST - 1 - (t - NBLK / 2), qc, mk[t - NBLK / 2], wl_lane, stg[t - NBLK / 2]);
+                if (t < NST) {
+                    if constexpr (Z) stage_mask_bz(qi, mv, mt, mr, so);
+                    else stage_mask_b(qi, mk[t], mt, so);
+                }
+                if (t >= NBLK / 2 && t < NBLK / 2 + NST) {
+                    if constexpr (Z)
+                        stage_commit(2 * (NST - 1 - (t - NBLK / 2)), qc, stage_mask_row(qc, SG), wl_lane, stg[t - NBLK / 2]);
+                    else
+                        stage_commit(NST - 1 - (t - NBLK / 2), qc, mk[t - NBLK / 2], wl_lane, stg[t - NBLK / 2]);
+                }
                 if (t >= E0 && t < E0 + MAXG) {
                     SRX_PIN(pd.acc[t - E0]);
-                    pipe_epilogue_one<MAXG, AUX, NPART>(pd, t - E0, ep, vst);
+                    pipe_epilogue_one<MAXG, AUX, NPART, Z>(pd, t - E0, ep, vst);
                 }
             } else if (ks == 2) {
 #pragma unroll
                 for (int i = 2; i < nfr; ++i) frag(i);
-                if (t < NST) stg[t] = stage_fire(mk[t], so, xrs, voff_lane);
+                if (t < NST) {
+                    if constexpr (Z) stg[t] = stage_fire_z(mv, mr, so, xrs, voff_lane);
+                    else stg[t] = stage_fire(mk[t], so, xrs, voff_lane);
+                }
                 if (t >= NBLK / 2 && t < NBLK / 2 + NST) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
             } else {
                 if (t < NST) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);
@@ -1031,8 +1114,12 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     tt[1] += SRX_STAMP() - ts_m;
 }
 
-template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
-__global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
+// Z = false: full-width tiles (a tile is TH whole rows of the image, units are output rows);
+// Z = true:  column strips of TW = 16 or 32 output columns with their own halo columns (units are the rows of a
+//            strip; the last strip of an image is shifted left to end at the image's edge, so every strip is TW wide
+//            and the columns two strips share are computed twice with identical results).
+template <int KH, int KW, int CINP, int NCH, bool WT, int AUX, bool Z>
+__device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TAPS = KH * KW;
     constexpr int KSPT = CINP / 4;
@@ -1080,7 +1167,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     // pixel 16m + (L & 15) of a tile, channel 4 * (L >> 4); it sits in pad word (L & 3) of slot 16m + (L >> 2).
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < (rows_full + 1) * a.pad_l * TPP; i += 256) {
+        for (int i = tid; !Z && i < (rows_full + 1) * a.pad_l * TPP; i += 256) {
             const int q = i / TPP, ch = i % TPP;
             const int r = q / a.pad_l, c = q % a.pad_l;
             const int off = ((r * a.RS + c) * PS + 4 * ch) * 4;
@@ -1089,13 +1176,14 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
                 *reinterpret_cast<f32x4*>(ldsb + buf_bytes + off) = z;
             }
         }
-        const int n_sub_max = (a.TH * a.OW + 15) >> 4;
+        const int tw_ = Z ? a.TW : a.OW;
+        const int n_sub_max = (a.TH * tw_ + 15) >> 4;
         for (int i = tid; i < n_sub_max * 64; i += 256) {
             const int m = i >> 6, L = i & 63;
             const int t = 16 * m + (L & 15);
             int addr = 0;
-            if (t < a.TH * a.OW) {
-                const int orow = t / a.OW, ocol = t - orow * a.OW;
+            if (t < a.TH * tw_) {
+                const int orow = t / tw_, ocol = t - orow * tw_;
                 addr = ((orow * a.RS + ocol) * PS + 4 * (L >> 4)) * 4;
             }
             const int where = ((16 * m + (L >> 2)) * PS + CINP + (L & 3)) * 4;
@@ -1115,23 +1203,37 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     SG.rowfix_l = __builtin_amdgcn_readfirstlane((a.RS - JP * PPP) * PS * 4);
     SG.m_first = uniform64(__ballot(sp >= a.pad_l));
     SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
+    SG.m_row = SG.m_last;
     const PipeEpi ep = pipe_epi_setup<AUX>(a);
     const float* auxp = a.mask ? a.mask : a.skip;
 
     // tile descriptor of unit u (wave-uniform)
-    auto tile_of = [&](int u, int& n, int& h, int& th) {
+    auto tile_of = [&](int u, int& n, int& h, int& th, int& ow0) {
         h = u % a.OH;
         n = u / a.OH;
+        ow0 = 0;
+        if constexpr (Z) {
+            const int tx = n % a.NTX;
+            n = n / a.NTX;
+            ow0 = tx * a.TW;
+            if (ow0 > a.OW - a.TW) ow0 = a.OW - a.TW;
+        }
         th = a.TH;
         if (a.OH - h < th) th = a.OH - h;
         if (u1 - u < th) th = u1 - u;
     };
     // cursors of a tile's staging: qi walks the image (issue), qc the LDS buffer (commit)
-    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int buf, bool active) {
+    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int ow0, int buf, bool active) {
         // (readfirstlane: once per tile, so that the cursors provably start out in SGPRs)
         const int left = __builtin_amdgcn_readfirstlane(active ? (th + KH - 1) * JP : 0);
         qi.j = 0; qc.j = 0;
-        qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+        qi.off = __builtin_amdgcn_readfirstlane(((h - a.pad_t) * a.W + ow0) * CINP * 4);
+        if constexpr (Z) {
+            // image column of tile slot c is ow0 - pad_l + c
+            SG.m_first = uniform64(__ballot(ow0 - a.pad_l + sp >= 0));
+            const int c = (JP - 1) * PPP + sp;
+            SG.m_last = uniform64(__ballot(c < a.RS && ow0 - a.pad_l + c < a.W));
+        }
         qc.off = __builtin_amdgcn_readfirstlane(buf * buf_bytes);
         qi.left = left; qc.left = left;
         const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;      // passes in rows above the image
@@ -1140,16 +1242,16 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     };
 
     unsigned long long tt[4] = {0, 0, 0, 0};   // trace: unit prologue, group sections, -, drain+barrier
-    int n, h, th;
-    tile_of(u0, n, h, th);
+    int n, h, th, ow0;
+    tile_of(u0, n, h, th, ow0);
     const unsigned long long t_begin = SRX_STAMP();
     __syncthreads();     // (set-up writes above vs. the first tile's writes below touch different bytes; this orders them with the reads)
     {
         StageSeq qi, qc;
-        stage_setup(qi, qc, h, th, 0, true);
+        stage_setup(qi, qc, h, th, ow0, 0, true);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
-        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);   // (6 loads in flight: the first tile is the only one whose latency is exposed)
+        stage_tile_scalar<CINP, 6, Z>(qi, qc, SG, xrs, voff_lane, wl_lane);   // (6 loads in flight: the first tile is the only one whose latency is exposed)
     }
     lds_barrier();
     // now move the weights into the accumulation-register file for good: they are defined as "a" values here and
@@ -1175,22 +1277,24 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
     int u = u0;
     while (u < u1) {
         const unsigned long long ts_u = SRX_STAMP();
-        tile_of(u, n, h, th);
+        tile_of(u, n, h, th, ow0);
         const int un_ = u + th;
         const bool has_next = un_ < u1;
-        int n2 = n, h2 = h, th2 = th;
-        if (has_next) tile_of(un_, n2, h2, th2);
+        int n2 = n, h2 = h, th2 = th, ow2 = ow0;
+        if (has_next) tile_of(un_, n2, h2, th2, ow2);
         StageSeq qi, qc;
-        stage_setup(qi, qc, h2, th2, cur_buf ^ 1, has_next);
+        stage_setup(qi, qc, h2, th2, ow2, cur_buf ^ 1, has_next);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.x) + ((size_t)n2 * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
 
         PipeUnit un;
-        const int npx = th * a.OW;
-        const size_t unit_off = ((size_t)n * a.OH + h) * a.OW * a.Cout;
-        un.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_off, 0, npx * ep.cout4, 0x00020000);
+        const int npx = th * (Z ? a.TW : a.OW);
+        const size_t unit_off = (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout;
+        // (strips: the unit's bytes run from its first pixel to the last pixel of its last row)
+        const int unit_bytes = (Z ? (th - 1) * a.OW + a.TW : npx) * ep.cout4;
+        un.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_off, 0, unit_bytes, 0x00020000);
         un.auxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AUX ? auxp + unit_off : a.x), 0,
-                                                     AUX ? npx * ep.cout4 : 0, 0x00020000);
+                                                     AUX ? unit_bytes : 0, 0x00020000);
 
         const int n_sub = (npx + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;
@@ -1210,24 +1314,24 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
                 const int gs = base + (gi < rem ? 1 : 0);
                 const int m_first = part + idx * NPART;
                 if (gs == MAXG)
-                    conv_group_pipe<KH, KW, CINP, MAXG, MAXG, AUX, NPART>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
+                    conv_group_pipe<KH, KW, CINP, MAXG, MAXG, AUX, NPART, Z>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
                                                                           wl_lane, la, cur, tcur, pd, un, m_first, gs, ep, vst, tt);
                 else
-                    conv_group_pipe<KH, KW, CINP, MAXG - 1, MAXG, AUX, NPART>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
+                    conv_group_pipe<KH, KW, CINP, MAXG - 1, MAXG, AUX, NPART, Z>(ldsb, wr, bias4, row_stride_b, qi, qc, SG, xrs, voff_lane,
                                                                               wl_lane, la, cur, tcur, pd, un, m_first, gs, ep, vst, tt);
                 idx += gs;
             }
         }
         // drain: whatever part of the next tile the groups did not cover
         const unsigned long long ts_d = SRX_STAMP();
-        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        stage_tile_scalar<CINP, 6, Z>(qi, qc, SG, xrs, voff_lane, wl_lane);
         lds_barrier();
         tt[3] += SRX_STAMP() - ts_d;
         cur_buf ^= 1;
         u = un_;
     }
 #pragma unroll
-    for (int i = 0; i < MAXG; ++i) pipe_epilogue_one<MAXG, AUX, NPART>(pd, i, ep, vst);
+    for (int i = 0; i < MAXG; ++i) pipe_epilogue_one<MAXG, AUX, NPART, Z>(pd, i, ep, vst);
 #ifdef SRX_TRACE
     if (a.trace && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
@@ -1237,6 +1341,17 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
         tr[8] = t_first - t_begin; tr[9] = 0; tr[10] = tt[0]; tr[11] = tt[2];
     }
 #endif
+}
+
+template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
+__global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
+    conv_pipe_body<KH, KW, CINP, NCH, WT, AUX, false>(a);
+}
+// the same for images too wide for full-width tiles: column strips
+template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
+__global__ __launch_bounds__(256, 1) void conv_pipe_strip_kernel(const ConvArgs a) {
+    static_assert(NCH == 4, "strip tiles: one sub-tile sequence per workgroup (NPART == 1)");
+    conv_pipe_body<KH, KW, CINP, NCH, WT, AUX, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ bool launch_conv_c4(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, h
 bool launch_conv_misc(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_pipe_other(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_pipe_strip(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
@@ -67,6 +68,21 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
             *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, true, 1>, a, grid, lds, s);        \
         else                                                                                              \
             *err = launch_with_lds(conv_pipe_kernel<KH, KW, CINP, NCH, true, 0>, a, grid, lds, s);        \
+        return true;                                                                                      \
+    }
+#define SRX_PIPE_STRIP_CASE(KH, KW, CINP, NCH)                                                            \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && !k.wt) {                            \
+        if (a.skip)                                                                                       \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 2>, a, grid, lds, s); \
+        else                                                                                              \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 0>, a, grid, lds, s); \
+        return true;                                                                                      \
+    }                                                                                                     \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && k.wt) {                             \
+        if (a.mask)                                                                                       \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, true, 1>, a, grid, lds, s);  \
+        else                                                                                              \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, true, 0>, a, grid, lds, s);  \
         return true;                                                                                      \
     }
 #define SRX_WGRAD_LIN_CASE(KH, KW, CINP, NCH, MINW)                                                       \

@@ -150,6 +150,19 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     const bool pipe_ok = epi_ok && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
                          16 * npart <= a.OW && (a.Cout & 3) == 0 &&
                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
+    // Column-strip variant (images too wide for full-width tiles): strips of 16 or 32 columns no wider than the
+    // image, one sub-tile sequence per workgroup (64 output channels); any padding.
+    const bool strip_ok = epi_ok && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
+                          p.RS >= ppp && npart == 1 && (a.Cout & 3) == 0 &&
+                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
+    if (g_use_pipe && p.cinp >= 16 && strip_ok) {
+        const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+        a.buf_floats = (int)(p.lds_bytes / 4);
+        if (launch_pipe_strip(k, a, pgrid, 2 * p.lds_bytes, s, &err)) {
+            if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+            return SRX_OK;
+        }
+    }
     if (g_use_pipe && p.cinp >= 16 && pipe_ok) {
         const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
         a.buf_floats = (int)(p.lds_bytes / 4);

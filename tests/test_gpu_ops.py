@@ -87,6 +87,13 @@ SHAPES = [
     (2, 100, 16, 3, 64, 64, 'SAME', None),
     (64, 5, 17, 3, 64, 64, 'SAME', 'relu'),      # many tiny images per workgroup
     (2, 7, 3, 3, 3, 64, 'SAME', 'relu'),
+    # column strips of the pipelined kernel (conv_pipe_strip_kernel): exact multiple of the strip width, a last
+    # strip shifted back over its neighbour, VALID geometry (no halo forward, two halo columns in dgrad), many
+    # short images
+    (2, 33, 64, 3, 64, 64, 'SAME', 'relu'),
+    (1, 9, 61, 3, 64, 64, 'SAME', None),
+    (1, 12, 80, 3, 64, 64, 'VALID', 'relu'),
+    (5, 4, 203, 3, 64, 64, 'SAME', 'relu'),
 ]
 
 
@@ -116,16 +123,17 @@ def test_conv_fwd_bwd_vs_oracle(shape, ops, conv_path):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-def test_conv_skip_and_post_relu(ops, conv_path):
+@pytest.mark.parametrize('width', [23, 77])       # full-width tiles / column strips
+def test_conv_skip_and_post_relu(width, ops, conv_path):
     rng = np.random.default_rng(7)
-    x = rng.uniform(-1, 1, (2, 19, 23, 64)).astype(np.float32)
+    x = rng.uniform(-1, 1, (2, 19, width, 64)).astype(np.float32)
     w = rng.normal(0, 0.05, (3, 3, 64, 64)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, (64,)).astype(np.float32)
     ref = O.c_conv2d_fwd(x, w, b, 'SAME', None, skip=x, post_relu=True)
     close(ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', None, skip=dev(x), post_add_relu=True), ref)
     # VDSR last layer: conv + bias + sd_images (3 channels)
     w3 = rng.normal(0, 0.05, (3, 3, 64, 3)).astype(np.float32)
-    sd = rng.uniform(-1, 1, (2, 19, 23, 3)).astype(np.float32)
+    sd = rng.uniform(-1, 1, (2, 19, width, 3)).astype(np.float32)
     ref = O.c_conv2d_fwd(x, w3, b[:3], 'SAME', None, skip=sd)
     close(ops.conv2d_fwd(dev(x), dev(w3), dev(b[:3]), 'same', None, skip=dev(sd)), ref)
 
