@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Forward-only VDSR-20 on whole images (the inference path of vdsr/experiment_resolve.py): HR megapixels/s by image
-size.  41-wide patches run on the pipelined kernels (full-width tiles); wide images are column-tiled and run on the
-two-workgroup kernels."""
+size.  41-wide patches run on the pipelined kernel with full-width tiles, wide images on its column-strip variant."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
