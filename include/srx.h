@@ -214,6 +214,18 @@ int srx_resize_bilinear(const float* in, float* out, int N, int H, int W, int C,
 int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f,
                          srx_stream_t stream);
 
+/* Gradient of srx_upsample_nearest (what TF's ResizeNearestNeighborGrad computes for an integer factor):
+ * din[n,h,w,c] = sum of the f x f block of dout.  dout [N,H*f,W*f,C] -> din [N,H,W,C].
+ * Backward of enet/enet/model_enet.py:78-80 inside the generator's training graph (:331-337). */
+int srx_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f,
+                             srx_stream_t stream);
+
+/* Gradient through t = relu(x + f(x)) of a residual block (enet/enet/model_enet.py:8-31) where the
+ * gradients via the skip path and via the conv path arrive separately:
+ * out = (y > 0) ? a + b : 0, y = the block input as saved (post-ReLU).  out may alias a or b. */
+int srx_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t numel,
+                      srx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ EXPORTS = [
     'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_act_bwd', 'srx_depth_to_space',
     'srx_space_to_depth', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
     'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
-    'srx_upsample_nearest',
+    'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
     L.srx_gaussian_blur.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
     L.srx_resize_bilinear.argtypes = [vp, vp, i, i, i, i, i, i, vp]
     L.srx_upsample_nearest.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srx_upsample_nearest_bwd.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srx_add_relu_grad.argtypes = [vp, vp, vp, vp, sz, vp]
     for name in EXPORTS:
         getattr(L, name)          # AttributeError if the library is stale
     _lib = L

@@ -27,4 +27,6 @@ hipError_t launch_affine(const float* x, float* out, size_t n, float a, float b,
 hipError_t launch_saturate_u8(const float* x, uint8_t* out, size_t n, hipStream_t s);
 hipError_t launch_psnr(const float* a, const float* b, float* out, int N, size_t per_image, float max_val, hipStream_t s);
 hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, hipStream_t s);
+hipError_t launch_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f, hipStream_t s);
+hipError_t launch_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t n, hipStream_t s);
 }  // namespace srx

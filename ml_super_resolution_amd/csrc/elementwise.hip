@@ -354,18 +354,75 @@ __global__ __launch_bounds__(256) void psnr_kernel(const float* __restrict__ a, 
         out[blockIdx.x] = 20.0f * log10f(max_val) - 10.0f * log10f(t / (float)per_image);
 }
 
+// Pixel replication and its gradient.  VEC floats per thread (4 when C is a multiple of 4: 16-byte accesses, a
+// wavefront covers whole pixels of the 64-channel tensors); one index decomposition per vector.
+template <int VEC>
 __global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                int N, int H, int W, int C, int f) {
-    const size_t total = (size_t)N * H * f * W * f * C;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * H * f * W * f * CV;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
-        const int c = (int)(o % C);
-        size_t t = o / C;
+        const int c = (int)(o % CV);
+        size_t t = o / CV;
         const int ow = (int)(t % ((size_t)W * f));
         t /= (size_t)W * f;
         const int oh = (int)(t % ((size_t)H * f));
         const int n = (int)(t / ((size_t)H * f));
-        out[o] = in[(((size_t)n * H + oh / f) * W + ow / f) * C + c];
+        const size_t src = (((size_t)n * H + oh / f) * W + ow / f) * CV + c;
+        if constexpr (VEC == 4)
+            reinterpret_cast<float4*>(out)[o] = reinterpret_cast<const float4*>(in)[src];
+        else
+            out[o] = in[src];
     }
+}
+
+// gradient of the replication: din[n,h,w,c] = sum over the f x f block of dout (rows, then columns, in order)
+template <int VEC>
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                   int N, int H, int W, int C, int f) {
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * H * W * CV;
+    const size_t orow = (size_t)W * f * CV;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int c = (int)(o % CV);
+        size_t t = o / CV;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const size_t base = (((size_t)n * H * f + (size_t)h * f) * W * f + (size_t)w * f) * CV + c;
+        if constexpr (VEC == 4) {
+            float4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int dy = 0; dy < f; ++dy)
+                for (int dx = 0; dx < f; ++dx) {
+                    const float4 v = reinterpret_cast<const float4*>(dout)[base + dy * orow + (size_t)dx * CV];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            reinterpret_cast<float4*>(din)[o] = acc;
+        } else {
+            float acc = 0.f;
+            for (int dy = 0; dy < f; ++dy)
+                for (int dx = 0; dx < f; ++dx) acc += dout[base + dy * orow + (size_t)dx * CV];
+            din[o] = acc;
+        }
+    }
+}
+
+// gradient through relu(a_in + b_in) where the two branches' gradients arrive separately:
+// out = (y > 0) ? a + b : 0   (residual block: gradient via the skip path + gradient via the conv path)
+__global__ __launch_bounds__(256) void add_relu_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ y, float* __restrict__ out, size_t n4,
+                                                            size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 va = reinterpret_cast<const float4*>(a)[i], vb = reinterpret_cast<const float4*>(b)[i];
+        const float4 vy = reinterpret_cast<const float4*>(y)[i];
+        float4 r;
+        r.x = vy.x > 0.f ? va.x + vb.x : 0.f; r.y = vy.y > 0.f ? va.y + vb.y : 0.f;
+        r.z = vy.z > 0.f ? va.z + vb.z : 0.f; r.w = vy.w > 0.f ? va.w + vb.w : 0.f;
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = y[i] > 0.f ? a[i] + b[i] : 0.f;
 }
 
 // SRCNN loss: one block per row computes ||pred-target||_2 of that row; a second pass scales.
@@ -582,8 +639,27 @@ hipError_t launch_psnr(const float* a, const float* b, float* out, int N, size_t
     return hipGetLastError();
 }
 hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, hipStream_t s) {
-    const size_t total = (size_t)N * H * f * W * f * C;
-    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, out, N, H, W, C, f);
+    const bool v4 = (C % 4) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    const size_t total = (size_t)N * H * f * W * f * (v4 ? C / 4 : C);
+    if (v4)
+        hipLaunchKernelGGL(upsample_nearest_kernel<4>, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, out, N, H, W, C, f);
+    else
+        hipLaunchKernelGGL(upsample_nearest_kernel<1>, dim3(ew_grid(total, 1)), dim3(256), 0, s, in, out, N, H, W, C, f);
+    return hipGetLastError();
+}
+hipError_t launch_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f, hipStream_t s) {
+    const bool v4 = (C % 4) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)din % 16) == 0;
+    const size_t total = (size_t)N * H * W * (v4 ? C / 4 : C);
+    if (v4)
+        hipLaunchKernelGGL(upsample_nearest_bwd_kernel<4>, dim3(ew_grid(total, 1)), dim3(256), 0, s, dout, din, N, H, W, C, f);
+    else
+        hipLaunchKernelGGL(upsample_nearest_bwd_kernel<1>, dim3(ew_grid(total, 1)), dim3(256), 0, s, dout, din, N, H, W, C, f);
+    return hipGetLastError();
+}
+hipError_t launch_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t n, hipStream_t s) {
+    const bool v4 = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y | (uintptr_t)out) % 16) == 0;
+    const size_t n4 = v4 ? n / 4 : 0;
+    hipLaunchKernelGGL(add_relu_grad_kernel, dim3(ew_grid(n4 ? n4 : n, 1)), dim3(256), 0, s, a, b, y, out, n4, n);
     return hipGetLastError();
 }
 

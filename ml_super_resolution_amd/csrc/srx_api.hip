@@ -507,4 +507,16 @@ int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C
     SRX_CHECK_LAUNCH(launch_upsample_nearest(in, out, N, H, W, C, f, (hipStream_t)stream), "upsample");
 }
 
+int srx_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f, srx_stream_t stream) {
+    if (!dout || !din) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || f <= 0) return fail(SRX_ERR_BAD_ARG, "bad upsample dims");
+    SRX_CHECK_LAUNCH(launch_upsample_nearest_bwd(dout, din, N, H, W, C, f, (hipStream_t)stream), "upsample_bwd");
+}
+
+int srx_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t numel, srx_stream_t stream) {
+    if (!a || !b || !y || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (numel == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_add_relu_grad(a, b, y, out, numel, (hipStream_t)stream), "add_relu_grad");
+}
+
 }  // extern "C"

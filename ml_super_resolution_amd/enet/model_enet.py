@@ -1,7 +1,8 @@
 """
 model_enet.py -- the EnhanceNet GENERATOR of enet/enet/model_enet.py (reference) on the MI355X
-engine: forward only (the discriminator, VGG-19 perceptual / texture losses and
-the GAN training loop are rows A14 / N4 and out of scope here).
+engine: forward, and the backward + Adam update of the generator variables for a given gradient on
+sr_images (the discriminator and the VGG-19 perceptual / texture losses that
+produce that gradient in the reference are rows A14 / N4 and not built).
 
   3x3 conv 3->64 ReLU                                   (model_enet.py:63-70)
   10 x residual_block: 3x3 ReLU -> 1x1 -> relu(x + .)   (:8-31, :74-75)
@@ -39,6 +40,7 @@ class EnetGenerator(object):
             self.kernels.append(w)
             self.biases.append(torch.zeros(cout, dtype=torch.float32, device=self.device))
         self.placeholders = {}
+        self._saved = None
 
     def variables(self):
         out = {}
@@ -53,22 +55,85 @@ class EnetGenerator(object):
             self.kernels[i].copy_(torch.as_tensor(k, dtype=torch.float32).to(self.device))
             self.biases[i].copy_(torch.as_tensor(b, dtype=torch.float32).to(self.device))
 
-    def forward(self, sd_images, bq_images):
-        """sd_images [N,h,w,3], bq_images [N,4h,4w,3] (bicubic-upscaled) -> sr_images [N,4h,4w,3]."""
+    def forward(self, sd_images, bq_images, keep=False):
+        """sd_images [N,h,w,3], bq_images [N,4h,4w,3] (bicubic-upscaled) -> sr_images [N,4h,4w,3].
+        keep=True saves what `backward` needs (the input of every conv; all of them post-ReLU tensors)."""
         K, B = self.kernels, self.biases
+        ins = [sd_images]                        # ins[i] = input of conv i
         t = ops.conv2d_fwd(sd_images, K[0], B[0], 'same', 'relu')
         i = 1
         for _ in range(10):
+            ins.append(t)
             x = ops.conv2d_fwd(t, K[i], B[i], 'same', 'relu')
+            ins.append(x)
             # 1x1 conv, + block input, ReLU -- one launch
             t = ops.conv2d_fwd(x, K[i + 1], B[i + 1], 'same', None, skip=t, post_add_relu=True)
             i += 2
         for _ in range(2):
             t = ops.upsample_nearest(t, 2)       # resize_nearest_neighbor to 2h then 4h = two doublings
+            ins.append(t)
             t = ops.conv2d_fwd(t, K[i], B[i], 'same', 'relu')
             i += 1
+        ins.append(t)
         t = ops.conv2d_fwd(t, K[i], B[i], 'same', 'relu')
+        ins.append(t)
+        self._saved = ins if keep else None
         return ops.conv2d_fwd(t, K[i + 1], B[i + 1], 'same', None, skip=bq_images)
+
+    def backward(self, d_sr):
+        """Gradients of every generator variable given d(loss)/d(sr_images) -- the part of
+        `g_trainer = AdamOptimizer(1e-4).minimize(g_losses, var_list=g_vars)` (model_enet.py:331-337) that runs
+        through the generator, whatever the loss on sr_images is.  Returns [(dkernel, dbias)] in layer order.
+
+        Every conv input is a post-ReLU tensor, so each data gradient is produced with the ReluGrad of the layer
+        below already applied (fused in the dgrad kernel's epilogue):
+          last conv / 4x convs:  plain chain, as in VDSR;
+          upsampling:            the mask is constant over a 2x2 block, so it is applied at the high resolution
+                                 (on the saved upsampled tensor) and the 2x2 block sum follows;
+          residual block t' = relu(t + conv1x1(relu(conv3x3(t)))): the incoming gradient g (already masked by
+                                 t' > 0) goes to the 1x1 conv and, unchanged, to the skip path; the block input's
+                                 gradient is (t > 0) ? g + dgrad3x3 : 0."""
+        if self._saved is None:
+            raise RuntimeError('backward() needs a forward(..., keep=True) first')
+        K, ins = self.kernels, self._saved
+        grads = [None] * len(K)
+
+        def wgrad(i, dpre):
+            grads[i] = ops.conv2d_bwd_filter(ins[i], dpre, K[i].shape, 'same')
+
+        i = len(K) - 1                           # 24: 64 -> 3, no activation
+        g = d_sr.contiguous()
+        wgrad(i, g)
+        g = ops.conv2d_bwd_data(g, K[i], ins[i].shape, 'same', x_in=ins[i], in_act='relu')
+        i -= 1                                   # 23: 3x3 ReLU at 4x
+        wgrad(i, g)
+        g = ops.conv2d_bwd_data(g, K[i], ins[i].shape, 'same', x_in=ins[i], in_act='relu')
+        for _ in range(2):                       # 22, 21: upsample -> 3x3 ReLU
+            i -= 1
+            wgrad(i, g)
+            g = ops.conv2d_bwd_data(g, K[i], ins[i].shape, 'same', x_in=ins[i], in_act='relu')
+            g = ops.upsample_nearest_bwd(g, 2)
+        for _ in range(10):                      # residual blocks, last to first
+            i -= 2                               # i = the block's 3x3 conv, i + 1 its 1x1 conv
+            wgrad(i + 1, g)
+            d3 = ops.conv2d_bwd_data(g, K[i + 1], ins[i + 1].shape, 'same', x_in=ins[i + 1], in_act='relu')
+            wgrad(i, d3)
+            via_conv = ops.conv2d_bwd_data(d3, K[i], ins[i].shape, 'same')
+            g = ops.add_relu_grad(g, via_conv, ins[i], out=via_conv)
+        wgrad(0, g)                              # first conv: its input is the fed image, no data gradient
+        return grads
+
+    def adam_step(self, grads, state, lr=1e-4):
+        """tf.train.AdamOptimizer(learning_rate=0.0001) on the g_ variables (model_enet.py:336-337); `state` is a
+        dict this method fills on first use (slots m, v and the step count)."""
+        if not state:
+            state['t'] = 0
+            state['m'] = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in zip(self.kernels, self.biases)]
+            state['v'] = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in zip(self.kernels, self.biases)]
+        state['t'] += 1
+        for i, (dw, db) in enumerate(grads):
+            ops.adam_tf_step(self.kernels[i], dw, state['m'][i][0], state['v'][i][0], lr, state['t'])
+            ops.adam_tf_step(self.biases[i], db, state['m'][i][1], state['v'][i][1], lr, state['t'])
 
     def run(self, keys, feed_dict):
         feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}

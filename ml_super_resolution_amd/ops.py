@@ -251,3 +251,24 @@ def upsample_nearest(x, f):
     out = torch.empty((N, H * f, W * f, C), dtype=torch.float32, device=x.device)
     check(lib().srx_upsample_nearest(_ptr(x), _ptr(out), N, H, W, C, f, _stream()), 'srx_upsample_nearest')
     return out
+
+
+def upsample_nearest_bwd(dout, f, out=None):
+    """Gradient of upsample_nearest: sums each f x f block.  dout [N,H*f,W*f,C] -> [N,H,W,C]."""
+    _chk(dout, 'dout')
+    N, HF, WF, C = dout.shape
+    if HF % f or WF % f:
+        raise ValueError('upsample_nearest_bwd: %dx%d is not a multiple of the factor %d' % (HF, WF, f))
+    out = out if out is not None else torch.empty((N, HF // f, WF // f, C), dtype=torch.float32, device=dout.device)
+    check(lib().srx_upsample_nearest_bwd(_ptr(dout), _ptr(out), N, HF // f, WF // f, C, f, _stream()), 'srx_upsample_nearest_bwd')
+    return out
+
+
+def add_relu_grad(a, b, y, out=None):
+    """(y > 0) ? a + b : 0 -- the gradient at the input of a residual block's closing ReLU chain."""
+    _chk(a, 'a'); _chk(b, 'b'); _chk(y, 'y')
+    if a.shape != b.shape or a.shape != y.shape:
+        raise ValueError('add_relu_grad: shapes differ')
+    out = out if out is not None else torch.empty_like(a)
+    check(lib().srx_add_relu_grad(_ptr(a), _ptr(b), _ptr(y), _ptr(out), a.numel(), _stream()), 'srx_add_relu_grad')
+    return out

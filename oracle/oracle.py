@@ -383,6 +383,65 @@ def vdsr_loss_and_grads(sd, hd, params, weight_decay=1e-4, numel_global=None, dt
     return mse + reg, grads, fwd
 
 
+def enet_generator_forward(sd, bq, params, dtype=np.float64, keep=False):
+    """enet/enet/model_enet.py:44-115 (+ residual_block :8-31).  params = [(kernel, bias)] * 25 in creation order:
+    3x3 3->64 ReLU; 10 x [3x3 ReLU, 1x1, + block input, ReLU]; 2 x [nearest x2, 3x3 ReLU]; 3x3 ReLU; 3x3 -> 3; + bq.
+    tf.image.resize_nearest_neighbor to an integer multiple (:78-80) replicates pixels.
+    keep=True also returns the input tensor of every conv (all of them post-ReLU except the fed image)."""
+    ins = [np.asarray(sd, dtype)]
+    t = conv2d_fwd(ins[0], *params[0], 'SAME', 'relu', dtype=dtype)
+    i = 1
+    for _ in range(10):
+        ins.append(t)
+        x = conv2d_fwd(t, *params[i], 'SAME', 'relu', dtype=dtype)
+        ins.append(x)
+        t = conv2d_fwd(x, *params[i + 1], 'SAME', None, skip=t, post_relu=True, dtype=dtype)
+        i += 2
+    for _ in range(2):
+        t = np.repeat(np.repeat(t, 2, axis=1), 2, axis=2)
+        ins.append(t)
+        t = conv2d_fwd(t, *params[i], 'SAME', 'relu', dtype=dtype)
+        i += 1
+    ins.append(t)
+    t = conv2d_fwd(t, *params[i], 'SAME', 'relu', dtype=dtype)
+    ins.append(t)
+    sr = conv2d_fwd(t, *params[i + 1], 'SAME', None, skip=np.asarray(bq, dtype), dtype=dtype)
+    return (sr, ins) if keep else sr
+
+
+def enet_generator_backward(ins, d_sr, params, dtype=np.float64):
+    """Gradients of the 25 (kernel, bias) pairs for a given d(loss)/d(sr_images): what TF's autodiff does for the
+    generator inside `g_trainer.minimize(g_losses, var_list=g_vars)` (enet/enet/model_enet.py:331-337):
+    ReluGrad = dy * [y > 0] on the post-ReLU tensor, ResizeNearestNeighborGrad = sum over each 2x2 block, the
+    residual sum passes its gradient to both branches.  `ins` from enet_generator_forward(..., keep=True)."""
+    grads = [None] * 25
+
+    def relu_mask(g, y):
+        return g * (y > 0)
+
+    def block_sum(g):
+        n, h, w, c = g.shape
+        return g.reshape(n, h // 2, 2, w // 2, 2, c).sum(axis=(2, 4))
+
+    g = np.asarray(d_sr, dtype)
+    for i in (24, 23):
+        k = params[i][0]
+        grads[i] = conv2d_bwd_filter(ins[i], g, k.shape[:2], 'SAME', dtype=dtype)
+        g = relu_mask(conv2d_bwd_data(g, k, ins[i].shape[1:3], 'SAME', dtype=dtype), ins[i])
+    for i in (22, 21):
+        k = params[i][0]
+        grads[i] = conv2d_bwd_filter(ins[i], g, k.shape[:2], 'SAME', dtype=dtype)
+        g = block_sum(relu_mask(conv2d_bwd_data(g, k, ins[i].shape[1:3], 'SAME', dtype=dtype), ins[i]))
+    for b in range(9, -1, -1):
+        i3, i1 = 1 + 2 * b, 2 + 2 * b
+        grads[i1] = conv2d_bwd_filter(ins[i1], g, (1, 1), 'SAME', dtype=dtype)
+        d3 = relu_mask(conv2d_bwd_data(g, params[i1][0], ins[i1].shape[1:3], 'SAME', dtype=dtype), ins[i1])
+        grads[i3] = conv2d_bwd_filter(ins[i3], d3, (3, 3), 'SAME', dtype=dtype)
+        g = relu_mask(g + conv2d_bwd_data(d3, params[i3][0], ins[i3].shape[1:3], 'SAME', dtype=dtype), ins[i3])
+    grads[0] = conv2d_bwd_filter(ins[0], g, (3, 3), 'SAME', dtype=dtype)
+    return grads
+
+
 def espcn_forward(lr, params, dtype=np.float64):
     """espcn/espcn/model_espcn.py:30-62 / :117-134: tanh, tanh, linear; all SAME."""
     (k1, b1), (k2, b2), (k3, b3) = params

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Times the three kernels of one 3x3 64->64 body layer (forward+ReLU, dgrad+ReluGrad, wgrad) at a few image
+sizes: 41-wide VDSR patches (full-width tiles) and the wide EnhanceNet / whole-image shapes (column strips).
+Usage: time_layer.py [N H W ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ml_super_resolution_amd import ops  # noqa: E402
+
+dev = torch.device('cuda')
+args = [int(v) for v in sys.argv[1:]]
+shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(256, 41, 41), (64, 64, 64), (16, 128, 128), (4, 256, 256), (1, 512, 512)]
+g = torch.Generator(device=dev).manual_seed(0)
+w = (torch.rand((3, 3, 64, 64), device=dev, generator=g) * 2 - 1) * 0.07
+b = torch.zeros(64, device=dev)
+for n, h, wd in shapes:
+    x = torch.rand((n, h, wd, 64), device=dev, generator=g) * 2 - 1
+    dy = torch.rand((n, h, wd, 64), device=dev, generator=g) * 2 - 1
+    y, dx, dw, db = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w), torch.empty(64, device=dev)
+    ws = torch.empty((ops.bwd_filter_workspace_bytes(x.shape, w.shape) + 3) // 4, device=dev)
+    fns = {
+        'fwd': lambda: ops.conv2d_fwd(x, w, b, 'same', 'relu', out=y),
+        'dgrad': lambda: ops.conv2d_bwd_data(dy, w, x.shape, 'same', x_in=x, in_act='relu', out=dx),
+        'wgrad': lambda: ops.conv2d_bwd_filter(x, dy, w.shape, 'same', w_for_decay=w, wd_scale=1e-4, dw=dw, dbias=db, workspace=ws),
+    }
+    flop = 2.0 * n * h * wd * 9 * 64 * 64
+    line = '%4d x %4d x %4d :' % (n, h, wd)
+    for name, fn in fns.items():
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        it = 10
+        s.record()
+        for _ in range(it):
+            fn()
+        e.record(); e.synchronize()
+        us = s.elapsed_time(e) / it * 1e3
+        line += '  %s %7.1f us %5.1f TF (%2.0f%%)' % (name, us, flop / us / 1e6, 100 * flop / us / 1e6 / 157.3)
+    print(line, flush=True)

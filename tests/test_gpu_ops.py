@@ -268,3 +268,24 @@ def test_errors_are_loud(ops):
         ops.conv2d_fwd(x, w)                       # Cin > 64: outside the kernel set -> error, not a fallback
     with pytest.raises(ValueError):
         ops.conv2d_fwd(torch.zeros(1, 8, 8, 3), torch.zeros(3, 3, 3, 64))   # CPU tensors rejected
+
+
+def test_upsample_bwd_and_add_relu_grad(ops):
+    rng = np.random.default_rng(77)
+    for shape, f in (((2, 5, 7, 64), 2), ((1, 3, 4, 3), 2), ((1, 2, 3, 8), 3)):
+        n, h, w, c = shape
+        x = rng.normal(0, 1, shape).astype(np.float32)
+        up = ops.upsample_nearest(dev(x), f)
+        np.testing.assert_array_equal(up.cpu().numpy(), np.repeat(np.repeat(x, f, axis=1), f, axis=2))
+        d = rng.normal(0, 1, (n, h * f, w * f, c)).astype(np.float32)
+        ref = np.zeros(shape, np.float32)
+        for dy in range(f):               # the kernel's summation order: rows, then columns
+            for dx in range(f):
+                ref = ref + d[:, dy::f, dx::f, :]
+        np.testing.assert_array_equal(ops.upsample_nearest_bwd(dev(d), f).cpu().numpy(), ref)
+    for numel in (1, 7, 4096, 64 * 41 * 41 + 3):
+        a, b, y = (rng.normal(0, 1, numel).astype(np.float32) for _ in range(3))
+        got = ops.add_relu_grad(dev(a), dev(b), dev(y)).cpu().numpy()
+        np.testing.assert_array_equal(got, np.where(y > 0, a + b, np.float32(0)))
+    with pytest.raises(ValueError):
+        ops.upsample_nearest_bwd(dev(np.zeros((1, 5, 4, 3), np.float32)), 2)
