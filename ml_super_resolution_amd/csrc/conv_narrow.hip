@@ -8,6 +8,8 @@
 // pixel issued loads of 64 scattered 16-byte pieces and was slower than the MFMA kernel.)
 #include "launchers.h"
 namespace srx {
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x3v __attribute__((ext_vector_type(3)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -82,6 +84,213 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long
             a.y[o] = r;
         }
     }
+}
+
+// The mirror case: THREE input channels, 64 output channels (the first layer 3x3 3->64 forward, and the data
+// gradient of the 64->3 output layer).  Bound by the write of the 64-channel tensor.  Same lane layout: 16 lanes
+// per pixel, four output channels each; the pixel's 3-channel neighbourhood arrives as nine 12-byte loads at a
+// lane-group-uniform address (bounds-checked: zero outside the image), the lane's 9 x 3 x 4 weights stay in
+// registers, the epilogue (bias, activation, residual, ReluGrad mask -- same order as the MFMA kernels) ends in one
+// 16-byte store per lane = 256 contiguous bytes per pixel.
+template <int KH, int KW, int CN, bool WT>
+__global__ __launch_bounds__(256) void conv_widen_kernel(const ConvArgs a, long total_px, int iters) {
+    static_assert(CN == 3, "12-byte pixel loads");
+    constexpr int TAPS = KH * KW, CW = 64;
+    const int c4 = threadIdx.x & 15;
+    const int sub = threadIdx.x >> 4;
+    float wr[TAPS][CN][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                wr[t][cn][e] = WT ? a.w[((size_t)(TAPS - 1 - t) * CW + 4 * c4 + e) * CN + cn]      // forward filter [kh,kw,64,3], flipped
+                                  : a.w[((size_t)t * CN + cn) * CW + 4 * c4 + e];
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * c4);
+    const float slope = act_slope(a.act), mslope = act_slope(a.mask_act);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
+                                                                         a.N * a.H * a.W * CN * 4, 0x00020000);
+    const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned p = p0 + (unsigned)it * 16u;
+        const bool live = p < (unsigned)total_px;
+        const unsigned pp = live ? p : 0u;
+        const unsigned t = pp / (unsigned)a.OW;
+        const int ow = (int)(pp - t * (unsigned)a.OW);
+        const int n = (int)(t / (unsigned)a.OH);
+        const int oh = (int)(t - (unsigned)n * (unsigned)a.OH);
+        const int img = n * a.H * a.W;
+        f32x3 v[TAPS];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
+                const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                const int off = ok ? (img + ih * a.W + iw) * CN * 4 : kOobOffset;
+                v[kh * KW + kw] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, off, 0, 0));
+            }
+        f32x4 acc = bias4;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[tp][cn], wr[tp][cn][e], acc[e]);
+        if (live) {
+            const size_t o = (size_t)p * CW + 4 * c4;
+            f32x4 r = act_apply4(acc, a.act, slope);
+            if (a.skip) r += *reinterpret_cast<const f32x4*>(a.skip + o);
+            if (a.post_relu) r = act_apply4(r, ACT_RELU, 0.0f);
+            if (a.mask) r = act_grad4(r, *reinterpret_cast<const f32x4*>(a.mask + o), a.mask_act, mslope);
+            *reinterpret_cast<f32x4*>(a.y + o) = r;
+        }
+    }
+}
+
+bool launch_conv_widen(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err) {
+    if (a.Cin != 3 || a.Cout != 64 || k.kh != 3 || k.kw != 3) return false;
+    if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) - 4096) return false;
+    const long total = (long)a.N * a.OH * a.OW;
+    if (total >= (1L << 31) - 4096) return false;
+    int iters = 16;
+    while (iters > 1 && total / (16L * iters) < 2048) iters >>= 1;
+    const long blocks = (total + 16L * iters - 1) / (16L * iters);
+    if (k.wt)
+        hipLaunchKernelGGL((conv_widen_kernel<3, 3, 3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, total, iters);
+    else
+        hipLaunchKernelGGL((conv_widen_kernel<3, 3, 3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, total, iters);
+    *err = hipGetLastError();
+    return true;
+}
+
+// Filter gradient of the same two layer shapes (3x3, 64 <-> 3 channels).  Same lane layout (16 lanes per output
+// position, four channels of the 64-channel tensor each); the 9 x 4 x 3 products of a position go into 108
+// per-lane accumulators, the bias gradient into 3 or 4 more.  A workgroup walks a contiguous range of positions,
+// then adds its 16 lane groups (xor-shuffles inside a wave, LDS across the four waves) and writes one partial
+// filter in the layout reduce_partials_kernel sums: HWIO gradient, then the bias gradient.
+// NOUT = true: Cin 64, Cout 3 (x is the wide tensor); false: Cin 3, Cout 64 (dpre is the wide tensor).
+template <int KH, int KW, bool NOUT>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, long total_px, int iters) {
+    constexpr int TAPS = KH * KW, CW = 64, CN = 3;
+    constexpr int NB = NOUT ? CN : 4;              // bias-gradient values per lane
+    constexpr int NV = TAPS * 4 * CN + NB;         // values per lane
+    __shared__ float red[4 * NV * 16];
+    const int c4 = threadIdx.x & 15;
+    const int sub = threadIdx.x >> 4;
+    const int wave = threadIdx.x >> 6;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, a.N * a.H * a.W * (NOUT ? CW : CN) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dpre), 0, a.N * a.OH * a.OW * (NOUT ? CN : CW) * 4, 0x00020000);
+    const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned p = p0 + (unsigned)it * 16u;
+        const bool live = p < (unsigned)total_px;
+        const unsigned pp = live ? p : 0u;
+        const unsigned t = pp / (unsigned)a.OW;
+        const int ow = (int)(pp - t * (unsigned)a.OW);
+        const int n = (int)(t / (unsigned)a.OH);
+        const int oh = (int)(t - (unsigned)n * (unsigned)a.OH);
+        const int img = n * a.H * a.W;
+        if constexpr (NOUT) {
+            const f32x3 d = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(drs, live ? (int)(p * CN * 4) : kOobOffset, 0, 0));
+            f32x4 v[TAPS];
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
+                    const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                    const int off = ok ? ((img + ih * a.W + iw) * CW + 4 * c4) * 4 : kOobOffset;
+                    v[kh * KW + kw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+                }
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < CN; ++c) acc[(tp * 4 + e) * CN + c] = fmaf(v[tp][e], d[c], acc[(tp * 4 + e) * CN + c]);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[TAPS * 4 * CN + c] += d[c];
+        } else {
+            const f32x4 d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                drs, live ? (int)((p * CW + 4 * c4) * 4) : kOobOffset, 0, 0));
+            f32x3 v[TAPS];
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
+                    const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                    const int off = ok ? (img + ih * a.W + iw) * CN * 4 : kOobOffset;
+                    v[kh * KW + kw] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, off, 0, 0));
+                }
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[(tp * CN + cn) * 4 + e] = fmaf(v[tp][cn], d[e], acc[(tp * CN + cn) * 4 + e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[TAPS * 4 * CN + e] += d[e];
+        }
+    }
+    // the wave's four lane groups, then the four waves
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float r = acc[i];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (sub % 4 == 0) red[(wave * NV + i) * 16 + c4] = r;
+    }
+    __syncthreads();
+    float* part = a.part + (size_t)blockIdx.x * a.part_stride;
+    const int wn = TAPS * CW * CN;
+    for (int q = threadIdx.x; q < NV * 16; q += 256) {
+        const int i = q >> 4, l = q & 15;
+        const float r = (red[(0 * NV + i) * 16 + l] + red[(1 * NV + i) * 16 + l]) +
+                        (red[(2 * NV + i) * 16 + l] + red[(3 * NV + i) * 16 + l]);
+        if (i < TAPS * 4 * CN) {
+            int idx;
+            if constexpr (NOUT) {                  // i = (tap * 4 + e) * 3 + c  ->  dW[tap][4l + e][c]
+                const int c = i % CN, te = i / CN, e = te & 3, tp = te >> 2;
+                idx = (tp * CW + 4 * l + e) * CN + c;
+            } else {                               // i = (tap * 3 + cn) * 4 + e  ->  dW[tap][cn][4l + e]
+                const int e = i & 3, tc = i >> 2;
+                idx = tc * CW + 4 * l + e;
+            }
+            part[idx] = r;
+        } else {
+            const int b = i - TAPS * 4 * CN;
+            if constexpr (NOUT) {
+                if (l == 0) part[wn + b] = r;      // (every lane of a pixel added the same three values)
+            } else {
+                part[wn + 4 * l + b] = r;
+            }
+        }
+    }
+}
+
+bool launch_wgrad_narrow(const ConvKey& k, const WgradArgs& a, int grid, hipStream_t s, hipError_t* err) {
+    if (k.kh != 3 || k.kw != 3) return false;
+    const bool nout = a.Cin == 64 && a.Cout == 3, nin = a.Cin == 3 && a.Cout == 64;
+    if (!nout && !nin) return false;
+    const long total = (long)a.N * a.OH * a.OW;
+    if (total >= (1L << 31) - 4096 || (long)a.N * a.H * a.W * 64 * 4 >= (1L << 31) - 4096 || total * 64 * 4 >= (1L << 31) - 4096)
+        return false;
+    const int iters = (int)((total + 16L * grid - 1) / (16L * grid));
+    if (nout)
+        hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3, true>), dim3(grid), dim3(256), 0, s, a, total, iters);
+    else
+        hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3, false>), dim3(grid), dim3(256), 0, s, a, total, iters);
+    *err = hipGetLastError();
+    return true;
 }
 
 bool launch_conv_narrow(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err) {

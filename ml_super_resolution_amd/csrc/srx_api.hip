@@ -138,12 +138,13 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // two LDS tile buffers (measured 7 % faster than the two-workgroups-per-CU kernels at 256x41x41x64).
     // SRX_PIPE=0 / srx_set_conv_path(0) selects the two-workgroup kernels for everything (A/B).
     if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
-    // Three output channels (the RGB output layers): one lane per pixel, no MFMA -- see conv_narrow.hip.
+    // Three output channels (the RGB output layer) or three input channels (the first layer, the output layer's
+    // data gradient): 16 lanes per pixel, no MFMA -- see conv_narrow.hip.
     // SRX_NARROW=0 keeps them on the MFMA kernels (A/B).
     {
         static int use_narrow = -1;
         if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
-        if (use_narrow && launch_conv_narrow(k, a, s, &err)) {
+        if (use_narrow && (launch_conv_narrow(k, a, s, &err) || launch_conv_widen(k, a, s, &err))) {
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
@@ -374,6 +375,12 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
             wdone = launch_wgrad_pipe(k, ap, wgrid, 2 * lin_lds, s, &err);
             if (!wdone) wgrid = p.grid;
         }
+    }
+    {
+        // 64 <-> 3 channel layers: 16 lanes per position, no MFMA (conv_narrow.hip); SRX_NARROW=0 for A/B
+        static int use_narrow = -1;
+        if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
+        if (!wdone && use_narrow) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
     }
     if (wdone) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
