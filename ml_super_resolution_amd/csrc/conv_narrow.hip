@@ -17,6 +17,43 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(moved);
 }
 
+// Output position of a 16-lane group, advanced by 16 positions per step without divisions.
+struct PixWalk {
+    int n, oh, ow;
+    __device__ __forceinline__ void init(unsigned p, int OH, int OW) {
+        const unsigned t = p / (unsigned)OW;
+        ow = (int)(p - t * (unsigned)OW);
+        n = (int)(t / (unsigned)OH);
+        oh = (int)(t - (unsigned)n * (unsigned)OH);
+    }
+    __device__ __forceinline__ void step16(int OH, int OW) {
+        ow += 16;
+        while (ow >= OW) {          // (at most once per step unless the image is narrower than 16 pixels)
+            ow -= OW;
+            oh += 1;
+            if (oh == OH) { oh = 0; n += 1; }
+        }
+    }
+};
+// Byte offsets of the KH x KW input pixels under an output position (pixel size PB bytes, plus `lane_b`), or the
+// out-of-range offset where the tap lies outside the image / the position is past the end: 3 + 3 range tests, then
+// one add and one select per tap.
+template <int KH, int KW>
+__device__ __forceinline__ void tap_offsets(int (&off)[KH * KW], const PixWalk& q, bool live, int H, int W, int pad_t, int pad_l,
+                                            int PB, int lane_b) {
+    const int centre = ((q.n * H + q.oh - pad_t) * W + (q.ow - pad_l)) * PB + lane_b;
+    bool rok[KH], cok[KW];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) rok[kh] = live && (unsigned)(q.oh + kh - pad_t) < (unsigned)H;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) cok[kw] = (unsigned)(q.ow + kw - pad_l) < (unsigned)W;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+            off[kh * KW + kw] = (rok[kh] && cok[kw]) ? centre + (kh * W + kw) * PB : kOobOffset;
+}
+
 template <int KH, int KW, int CIN, int CO>
 __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long total_px, int iters) {
     static_assert(CIN == 64, "16 lanes x 4 channels per pixel");
@@ -37,25 +74,17 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
                                                                          a.N * a.H * a.W * CIN * 4, 0x00020000);
     const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;      // (pixel indices fit 31 bits: host-checked)
-    for (int it = 0; it < iters; ++it) {
+    PixWalk q;
+    q.init(p0 < (unsigned)total_px ? p0 : 0u, a.OH, a.OW);
+    for (int it = 0; it < iters; ++it, q.step16(a.OH, a.OW)) {
         const unsigned p = p0 + (unsigned)it * 16u;
         const bool live = p < (unsigned)total_px;  // (uniform over the 16 lanes of a pixel)
-        const unsigned pp = live ? p : 0u;
-        const unsigned t = pp / (unsigned)a.OW;
-        const int ow = (int)(pp - t * (unsigned)a.OW);
-        const int n = (int)(t / (unsigned)a.OH);
-        const int oh = (int)(t - (unsigned)n * (unsigned)a.OH);
-        const int img = n * a.H * a.W;
+        int off[TAPS];
+        tap_offsets<KH, KW>(off, q, live, a.H, a.W, a.pad_t, a.pad_l, CIN * 4, 16 * c4);
         f32x4 v[TAPS];
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
-                const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const int off = ok ? ((img + ih * a.W + iw) * CIN + 4 * c4) * 4 : kOobOffset;
-                v[kh * KW + kw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
-            }
+        for (int tp = 0; tp < TAPS; ++tp)
+            v[tp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off[tp], 0, 0));
         float acc[CO];
 #pragma unroll
         for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
@@ -86,86 +115,6 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long
     }
 }
 
-// The mirror case: THREE input channels, 64 output channels (the first layer 3x3 3->64 forward, and the data
-// gradient of the 64->3 output layer).  Bound by the write of the 64-channel tensor.  Same lane layout: 16 lanes
-// per pixel, four output channels each; the pixel's 3-channel neighbourhood arrives as nine 12-byte loads at a
-// lane-group-uniform address (bounds-checked: zero outside the image), the lane's 9 x 3 x 4 weights stay in
-// registers, the epilogue (bias, activation, residual, ReluGrad mask -- same order as the MFMA kernels) ends in one
-// 16-byte store per lane = 256 contiguous bytes per pixel.
-template <int KH, int KW, int CN, bool WT>
-__global__ __launch_bounds__(256) void conv_widen_kernel(const ConvArgs a, long total_px, int iters) {
-    static_assert(CN == 3, "12-byte pixel loads");
-    constexpr int TAPS = KH * KW, CW = 64;
-    const int c4 = threadIdx.x & 15;
-    const int sub = threadIdx.x >> 4;
-    float wr[TAPS][CN][4];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int cn = 0; cn < CN; ++cn)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                wr[t][cn][e] = WT ? a.w[((size_t)(TAPS - 1 - t) * CW + 4 * c4 + e) * CN + cn]      // forward filter [kh,kw,64,3], flipped
-                                  : a.w[((size_t)t * CN + cn) * CW + 4 * c4 + e];
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * c4);
-    const float slope = act_slope(a.act), mslope = act_slope(a.mask_act);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
-                                                                         a.N * a.H * a.W * CN * 4, 0x00020000);
-    const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;
-    for (int it = 0; it < iters; ++it) {
-        const unsigned p = p0 + (unsigned)it * 16u;
-        const bool live = p < (unsigned)total_px;
-        const unsigned pp = live ? p : 0u;
-        const unsigned t = pp / (unsigned)a.OW;
-        const int ow = (int)(pp - t * (unsigned)a.OW);
-        const int n = (int)(t / (unsigned)a.OH);
-        const int oh = (int)(t - (unsigned)n * (unsigned)a.OH);
-        const int img = n * a.H * a.W;
-        f32x3 v[TAPS];
-#pragma unroll
-        for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
-                const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const int off = ok ? (img + ih * a.W + iw) * CN * 4 : kOobOffset;
-                v[kh * KW + kw] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, off, 0, 0));
-            }
-        f32x4 acc = bias4;
-#pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-            for (int cn = 0; cn < CN; ++cn)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[tp][cn], wr[tp][cn][e], acc[e]);
-        if (live) {
-            const size_t o = (size_t)p * CW + 4 * c4;
-            f32x4 r = act_apply4(acc, a.act, slope);
-            if (a.skip) r += *reinterpret_cast<const f32x4*>(a.skip + o);
-            if (a.post_relu) r = act_apply4(r, ACT_RELU, 0.0f);
-            if (a.mask) r = act_grad4(r, *reinterpret_cast<const f32x4*>(a.mask + o), a.mask_act, mslope);
-            *reinterpret_cast<f32x4*>(a.y + o) = r;
-        }
-    }
-}
-
-bool launch_conv_widen(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err) {
-    if (a.Cin != 3 || a.Cout != 64 || k.kh != 3 || k.kw != 3) return false;
-    if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) - 4096) return false;
-    const long total = (long)a.N * a.OH * a.OW;
-    if (total >= (1L << 31) - 4096) return false;
-    int iters = 16;
-    while (iters > 1 && total / (16L * iters) < 2048) iters >>= 1;
-    const long blocks = (total + 16L * iters - 1) / (16L * iters);
-    if (k.wt)
-        hipLaunchKernelGGL((conv_widen_kernel<3, 3, 3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, total, iters);
-    else
-        hipLaunchKernelGGL((conv_widen_kernel<3, 3, 3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, total, iters);
-    *err = hipGetLastError();
-    return true;
-}
-
 // Filter gradient of the same two layer shapes (3x3, 64 <-> 3 channels).  Same lane layout (16 lanes per output
 // position, four channels of the 64-channel tensor each); the 9 x 4 x 3 products of a position go into 108
 // per-lane accumulators, the bias gradient into 3 or 4 more.  A workgroup walks a contiguous range of positions,
@@ -189,27 +138,19 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, lo
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.dpre), 0, a.N * a.OH * a.OW * (NOUT ? CN : CW) * 4, 0x00020000);
     const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;
-    for (int it = 0; it < iters; ++it) {
+    PixWalk q;
+    q.init(p0 < (unsigned)total_px ? p0 : 0u, a.OH, a.OW);
+    for (int it = 0; it < iters; ++it, q.step16(a.OH, a.OW)) {
         const unsigned p = p0 + (unsigned)it * 16u;
         const bool live = p < (unsigned)total_px;
-        const unsigned pp = live ? p : 0u;
-        const unsigned t = pp / (unsigned)a.OW;
-        const int ow = (int)(pp - t * (unsigned)a.OW);
-        const int n = (int)(t / (unsigned)a.OH);
-        const int oh = (int)(t - (unsigned)n * (unsigned)a.OH);
-        const int img = n * a.H * a.W;
+        int off[TAPS];
+        tap_offsets<KH, KW>(off, q, live, a.H, a.W, a.pad_t, a.pad_l, (NOUT ? CW : CN) * 4, NOUT ? 16 * c4 : 0);
         if constexpr (NOUT) {
             const f32x3 d = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(drs, live ? (int)(p * CN * 4) : kOobOffset, 0, 0));
             f32x4 v[TAPS];
 #pragma unroll
-            for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
-                    const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                    const int off = ok ? ((img + ih * a.W + iw) * CW + 4 * c4) * 4 : kOobOffset;
-                    v[kh * KW + kw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
-                }
+            for (int tp = 0; tp < TAPS; ++tp)
+                v[tp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off[tp], 0, 0));
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -223,14 +164,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, lo
                 drs, live ? (int)((p * CW + 4 * c4) * 4) : kOobOffset, 0, 0));
             f32x3 v[TAPS];
 #pragma unroll
-            for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    const int ih = oh + kh - a.pad_t, iw = ow + kw - a.pad_l;
-                    const bool ok = live && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                    const int off = ok ? (img + ih * a.W + iw) * CN * 4 : kOobOffset;
-                    v[kh * KW + kw] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, off, 0, 0));
-                }
+            for (int tp = 0; tp < TAPS; ++tp)
+                v[tp] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, off[tp], 0, 0));
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll

@@ -18,7 +18,6 @@ bool launch_conv_misc(const ConvKey& k, const ConvArgs& a, int grid, size_t lds,
 bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_pipe_other(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_narrow(const ConvKey& k, const WgradArgs& a, int grid, hipStream_t s, hipError_t* err);
-bool launch_conv_widen(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err);
 bool launch_conv_narrow(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err);
 bool launch_pipe_strip(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);

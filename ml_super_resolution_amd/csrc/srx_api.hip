@@ -138,13 +138,13 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // two LDS tile buffers (measured 7 % faster than the two-workgroups-per-CU kernels at 256x41x41x64).
     // SRX_PIPE=0 / srx_set_conv_path(0) selects the two-workgroup kernels for everything (A/B).
     if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
-    // Three output channels (the RGB output layer) or three input channels (the first layer, the output layer's
-    // data gradient): 16 lanes per pixel, no MFMA -- see conv_narrow.hip.
+    // Three output channels (the RGB output layer): 16 lanes per pixel, no MFMA -- see conv_narrow.hip.  (The
+    // mirror case, 3 -> 64 channels, was tried the same way and lost to the MFMA kernel: 56 vs 48 us.)
     // SRX_NARROW=0 keeps them on the MFMA kernels (A/B).
     {
         static int use_narrow = -1;
         if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
-        if (use_narrow && (launch_conv_narrow(k, a, s, &err) || launch_conv_widen(k, a, s, &err))) {
+        if (use_narrow && launch_conv_narrow(k, a, s, &err)) {
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
