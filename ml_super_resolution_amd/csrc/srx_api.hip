@@ -165,6 +165,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // image, one sub-tile sequence per workgroup (64 output channels); any padding.
     const bool strip_ok = epi_ok && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
                           p.RS >= ppp && npart == 1 && (a.Cout & 3) == 0 &&
+                          a.y != a.skip && a.y != a.mask &&   // (the columns two strips share are computed twice: no in-place epilogue operand)
                           (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     if (g_use_pipe && p.cinp >= 16 && strip_ok) {
         const int pgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;

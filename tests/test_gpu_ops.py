@@ -131,6 +131,12 @@ def test_conv_skip_and_post_relu(width, ops, conv_path):
     b = rng.uniform(-0.1, 0.1, (64,)).astype(np.float32)
     ref = O.c_conv2d_fwd(x, w, b, 'SAME', None, skip=x, post_relu=True)
     close(ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', None, skip=dev(x), post_add_relu=True), ref)
+    # residual operand updated in place (out aliases skip): allowed; on wide images the strip kernel, which computes
+    # shared columns twice, must not be chosen for it
+    t = dev(x).clone()
+    got = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', None, skip=t, post_add_relu=True, out=t)
+    assert got.data_ptr() == t.data_ptr()
+    close(got, ref)
     # VDSR last layer: conv + bias + sd_images (3 channels)
     w3 = rng.normal(0, 0.05, (3, 3, 64, 3)).astype(np.float32)
     sd = rng.uniform(-1, 1, (2, 19, width, 3)).astype(np.float32)
