@@ -94,6 +94,14 @@ SHAPES = [
     (1, 9, 61, 3, 64, 64, 'SAME', None),
     (1, 12, 80, 3, 64, 64, 'VALID', 'relu'),
     (5, 4, 203, 3, 64, 64, 'SAME', 'relu'),
+    # the 16-lanes-per-position kernels of the 64 <-> 3 channel layers (conv_narrow.hip): rows shorter than one
+    # 16-position step, VALID geometry, a 1x1 image, a wide image, many positions per workgroup
+    (3, 6, 9, 3, 64, 3, 'VALID', 'tanh'),
+    (1, 1, 1, 3, 64, 3, 'SAME', None),
+    (2, 50, 97, 3, 64, 3, 'SAME', None),
+    (3, 6, 9, 3, 3, 64, 'VALID', 'relu'),
+    (40, 41, 41, 3, 3, 64, 'SAME', 'relu'),
+    (40, 41, 41, 3, 64, 3, 'SAME', None),
 ]
 
 
