@@ -327,13 +327,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n,
                                                      float a, float b) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        out[i] = a * x[i] + b;
+    {
+#pragma clang fp contract(off)
+        const float t = a * x[i];                    // two roundings, like the reference's separate multiply and add
+        out[i] = t + b;
+    }
 }
 
 __global__ __launch_bounds__(256) void saturate_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
                                                           size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = x[i] * 127.5f + 127.5f;
+        // multiply and add rounded separately, as the two TensorFlow ops are (a fused multiply-add rounds once and
+        // moves a few values across an integer, i.e. changes the truncated byte)
+#pragma clang fp contract(off)
+        float v = x[i] * 127.5f;
+        v = v + 127.5f;
         v = fminf(fmaxf(v, 0.f), 255.f);
         out[i] = (uint8_t)v;  // truncation toward zero, as tf.saturate_cast
     }

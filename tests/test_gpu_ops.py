@@ -219,6 +219,21 @@ def test_mse_l2_adam_momentum_psnr(ops):
     close(ops.psnr(dev(a), dev(b), 2.0), O.psnr(a, b, 2.0), 1e-5)
     xs = np.array([-2.0, -1.0, 0.0, 0.999, 1.0, 3.0, 0.5, -0.5], np.float32)
     np.testing.assert_array_equal(ops.saturate_u8(dev(xs)).cpu().numpy(), O.saturate_u8(xs))
+    # bit-exact bytes: every uint8 level mapped to [-1, 1] the way the reference's readers do (/127.5 - 1 and
+    # /255 * 2 - 1), and floats a few ulps either side of every integer boundary of x * 127.5 + 127.5
+    lv = np.arange(256, dtype=np.float32)
+    cases = [lv / np.float32(127.5) - np.float32(1.0), lv / np.float32(255.0) * np.float32(2.0) - np.float32(1.0)]
+    edge = (lv - np.float32(127.5)) / np.float32(127.5)
+    for k in range(-3, 4):
+        e = edge.copy()
+        for _ in range(abs(k)):
+            e = np.nextafter(e, np.float32(np.inf if k > 0 else -np.inf))
+        cases.append(e)
+    cases.append(rng.uniform(-1.2, 1.2, 100000).astype(np.float32))
+    for c in cases:
+        np.testing.assert_array_equal(ops.saturate_u8(dev(c)).cpu().numpy(), O.saturate_u8(c))
+        ref = c * np.float32(127.5) + np.float32(127.5)
+        np.testing.assert_array_equal(ops.affine(dev(c), 127.5, 127.5).cpu().numpy(), ref)
 
 
 def test_ssim_vs_oracle(ops):
