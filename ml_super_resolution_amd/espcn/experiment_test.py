@@ -70,8 +70,8 @@ def psnr_in_subpixel_space(model, sr_results, hr_targets, score_space='y'):
 def super_resolve_array(model, lr_image):
     """experiment_test.py:159-181 on a decoded image: [h,w,3] uint8 -> [h*r,w*r,3] float in [0,1]."""
     m = model['_model']
-    lr = torch.from_numpy(np.ascontiguousarray(lr_image, dtype=np.float32)).to(m.stack.device)
-    lr = ops.affine(lr.unsqueeze(0).contiguous(), 1.0 / 127.5, -1.0)
+    # (:160) `lr_image / 127.5 - 1.0` on the uint8 array is float64 arithmetic, cast to float32 when fed
+    lr = torch.from_numpy((np.asarray(lr_image) / 127.5 - 1.0).astype(np.float32)[None]).to(m.stack.device)
     sr = m.super_resolve(lr)                                   # conv stack + depth-to-space on the GPU
     sr = ops.affine(sr, 0.5, 0.5).clamp_(0.0, 1.0)
     return sr[0].cpu().numpy()

@@ -40,6 +40,16 @@ def test_espcn_test_model_and_d2s(r, golden_nets, tmp_path):
     lab = experiment_test.space_to_depth_numpy(hr[0], r)
     np.testing.assert_array_equal(lab, sr[0])
     np.testing.assert_array_equal(ops.space_to_depth(dev(hr), r).cpu().numpy(), sr)
+    # whole-image path of experiment_test.py:159-181: uint8 image -> [-1,1] (float64 arithmetic, as numpy does for
+    # uint8 / 127.5) -> net -> depth-to-space -> * 0.5 + 0.5 -> clip
+    img = np.random.default_rng(r).integers(0, 256, (11, 9, 3), dtype=np.uint8)
+    got = experiment_test.super_resolve_array(model, img)
+    lr_ref = (img / 127.5 - 1.0).astype(np.float32)[None]
+    y_ref = O.espcn_forward(lr_ref, params)
+    y_ref = np.asarray(y_ref['sr_result'] if isinstance(y_ref, dict) else y_ref)
+    want = np.clip(O.depth_to_space(y_ref, r)[0] * 0.5 + 0.5, 0.0, 1.0)
+    assert got.shape == (11 * r, 9 * r, 3)
+    close(got, want)
 
 
 def test_espcn_train_step_vs_oracle():
