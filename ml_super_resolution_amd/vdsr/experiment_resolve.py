@@ -31,9 +31,11 @@ def main(argv=None):
     hd = np.asarray(Image.open(FLAGS.hd_image_path).convert('RGB')).astype(np.float32) / 255.0
     if FLAGS.ground_truth_mode:
         sd = dataset.hd_image_to_sd_image(hd, FLAGS.scaling_factor)
-    else:   # plain upscaling of the given image by scaling_factor (experiment_resolve.py:28-35)
-        big = np.zeros((int(hd.shape[0] * FLAGS.scaling_factor), int(hd.shape[1] * FLAGS.scaling_factor), 3), np.float32)
-        sd = dataset.hd_image_to_sd_image(np.pad(hd, ((0, big.shape[0] - hd.shape[0]), (0, big.shape[1] - hd.shape[1]), (0, 0)), mode='edge'), 1.0)
+    else:
+        # plain up-scaling of the given image: skimage.transform.resize(hd, [int(s*h), int(s*w)], mode='edge',
+        # anti_aliasing=False) (experiment_resolve.py:28-35) = the device bilinear resize of row N1
+        hd_dev = torch.from_numpy(np.ascontiguousarray(hd[None])).to(device)
+        sd = ops.resize_bilinear(hd_dev, int(FLAGS.scaling_factor * hd.shape[0]), int(FLAGS.scaling_factor * hd.shape[1]))[0].cpu().numpy()
     sd_t = torch.from_numpy((sd * 2.0 - 1.0)[None].astype(np.float32)).to(device)
     sr = model.forward(sd_t)
     Image.fromarray(ops.saturate_u8(sr)[0].cpu().numpy()).save(FLAGS.sr_image_path)
