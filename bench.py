@@ -45,6 +45,19 @@ def hip_event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all of
+    the host's logical CPUs but grants a share of them; one thread per visible CPU would only oversubscribe it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rank):
     """The oracle's C restatement ("port") timed on this host's cores on a bounded sample of the
     same workload: forward + backward of VDSR-20 on a few 41x41 patches."""
@@ -57,7 +70,8 @@ def cpu_baseline(rank):
         subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
     rng = np.random.default_rng(106)
     params = [(O.xavier_uniform(rng, ks), np.zeros(bs, np.float32)) for ks, bs in O.vdsr_param_shapes(20)]
-    cores = O.clib().srx_ref_num_threads()
+    # one thread per CPU the process is granted (torch has initialised OpenMP with one per visible CPU already)
+    cores = O.clib().srx_ref_set_num_threads(usable_cpus())
     n = max(4, cores)                      # a few patches per core
     hd = np.random.default_rng(104).uniform(-1, 1, (n, SIZE, SIZE, 3)).astype(np.float32)
     sd = np.clip(hd + 0.1 * np.random.default_rng(105).normal(0, 1, hd.shape), -1, 1).astype(np.float32)
@@ -72,6 +86,50 @@ def cpu_baseline(rank):
             break
     return {'value': round(n * reps / dt, 3), 'unit': 'patches/s', 'cores': int(cores), 'kind': 'port',
             'sample': '%d x VDSR-20 fwd+bwd on %d patches of 41x41 (oracle/srx_oracle.c, OpenMP, fp32)' % (reps, n)}
+
+
+def cpu_library_baseline(rank):
+    """Second CPU comparator: the same VDSR-20 forward + backward through torch's CPU convolutions
+    (oneDNN, all host cores) -- the optimised-library stand-in closest to what the reference's TensorFlow-Eigen CPU
+    path would do.  Neither the reference nor a port of it: reported beside `cpu_baseline`, never instead of it."""
+    if rank != 0:
+        return None
+    try:
+        import torch.nn.functional as F
+        threads = usable_cpus()
+        torch.set_num_threads(threads)
+        g = torch.Generator().manual_seed(106)
+        ws = [torch.randn((64 if i < 19 else 3, 3 if i == 0 else 64, 3, 3), generator=g) * 0.05 for i in range(20)]
+        bs = [torch.zeros(w.shape[0]) for w in ws]
+        for t in ws + bs:
+            t.requires_grad_(True)
+        n = max(32, min(256, threads))
+        hd = torch.rand((n, 3, SIZE, SIZE), generator=g) * 2 - 1
+        sd = (hd + 0.1 * torch.randn(hd.shape, generator=g)).clamp(-1, 1)
+
+        def step():
+            t = sd
+            for i in range(19):
+                t = F.relu(F.conv2d(t, ws[i], bs[i], padding=1))
+            sr = sd + F.conv2d(t, ws[19], bs[19], padding=1)
+            loss = F.mse_loss(sr, hd)
+            loss.backward()
+            for t_ in ws + bs:
+                t_.grad = None
+
+        step()
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            step()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 8.0 or reps >= 6:
+                break
+        return {'value': round(n * reps / dt, 2), 'unit': 'patches/s', 'cores': int(threads), 'kind': 'library stand-in',
+                'sample': '%d x VDSR-20 fwd+bwd on %d patches of 41x41 (torch %s CPU conv2d + autograd, fp32)' % (reps, n, torch.__version__)}
+    except Exception as exc:     # a comparator, not part of the measurement
+        return {'value': None, 'error': repr(exc)}
 
 
 def main():
@@ -173,6 +231,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rank)
+            line['cpu_library_baseline'] = cpu_library_baseline(rank)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

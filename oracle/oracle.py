@@ -514,6 +514,8 @@ def clib():
         L.srx_ref_psnr.argtypes = [fp, fp, fp, i, ctypes.c_size_t, ctypes.c_float]
         L.srx_ref_saturate_u8.argtypes = [fp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t]
         L.srx_ref_num_threads.restype = i
+        L.srx_ref_set_num_threads.argtypes = [i]
+        L.srx_ref_set_num_threads.restype = i
         _clib = L
     return _clib
 

@@ -58,6 +58,17 @@ int srx_ref_num_threads(void) {
 #endif
 }
 
+/* the timing leg of bench.py sizes the thread pool to the CPUs the process is really granted */
+int srx_ref_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 static inline float act_apply(float v, int act) {
     switch (act) {
     case SRX_REF_ACT_RELU:    return v > 0.0f ? v : 0.0f;
