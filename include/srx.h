@@ -113,6 +113,18 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
                           float* dbias, const float* w_for_decay, float wd_scale, void* ws,
                           size_t ws_bytes, srx_stream_t stream);
 
+/* The same in two calls, for callers that want the (HBM-bound) reduction of the per-workgroup partials to run
+ * on another stream than the (MFMA-bound) gradient kernel -- e.g. under the next layer's dgrad:
+ *   srx_conv2d_bwd_filter_partials   fills `ws` with *n_partials partial filters;
+ *   srx_conv2d_bwd_filter_reduce     sums them in a fixed order into dw / dbias (+ the regulariser term).
+ * The caller orders the two (event / stream wait) and keeps `ws` untouched in between.
+ * srx_conv2d_bwd_filter(...) == partials + reduce on one stream, bit for bit. */
+int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const float* dpre, void* ws,
+                                   size_t ws_bytes, int* n_partials, srx_stream_t stream);
+int srx_conv2d_bwd_filter_reduce(const srx_conv_desc* d, const void* ws, int n_partials, float* dw,
+                                 float* dbias, const float* w_for_decay, float wd_scale,
+                                 srx_stream_t stream);
+
 /* dpre = dy * act'(y)  (ReluGrad / TanhGrad on the post-activation tensor). */
 int srx_act_bwd(const float* dy, const float* y, float* dpre, size_t numel, int act,
                 srx_stream_t stream);

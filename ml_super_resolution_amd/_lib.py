@@ -21,7 +21,7 @@ PAD_BY_NAME = {'same': PAD_SAME, 'valid': PAD_VALID}
 # every symbol include/srx.h declares
 EXPORTS = [
     'srx_version', 'srx_last_error', 'srx_set_conv_path', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
-    'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_act_bwd', 'srx_depth_to_space',
+    'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_conv2d_bwd_filter_partials', 'srx_conv2d_bwd_filter_reduce', 'srx_act_bwd', 'srx_depth_to_space',
     'srx_space_to_depth', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
     'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
     'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
@@ -62,6 +62,8 @@ def lib():
     L.srx_conv2d_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.srx_conv2d_bwd_data.argtypes = [dp, vp, vp, vp, i, vp, vp, sz, vp]
     L.srx_conv2d_bwd_filter.argtypes = [dp, vp, vp, vp, vp, vp, f, vp, sz, vp]
+    L.srx_conv2d_bwd_filter_partials.argtypes = [dp, vp, vp, vp, sz, ctypes.POINTER(ctypes.c_int), vp]
+    L.srx_conv2d_bwd_filter_reduce.argtypes = [dp, vp, i, vp, vp, vp, f, vp]
     L.srx_act_bwd.argtypes = [vp, vp, vp, sz, i, vp]
     L.srx_depth_to_space.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srx_space_to_depth.argtypes = [vp, vp, i, i, i, i, i, vp]

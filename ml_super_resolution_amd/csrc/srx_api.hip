@@ -311,18 +311,17 @@ int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* 
     return dispatch_conv(p, true, a, (hipStream_t)stream, ws, ws_bytes);
 }
 
-int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* dpre, float* dw, float* dbias,
-                          const float* w_for_decay, float wd_scale, void* ws, size_t ws_bytes, srx_stream_t stream) {
+int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const float* dpre, void* ws, size_t ws_bytes,
+                                   int* n_partials, srx_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!x || !dpre || !dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (!x || !dpre || !n_partials) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
     if (!aligned16(x) || !aligned16(dpre)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
     rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
     if (rc) return rc;
-    const size_t wn = (size_t)d->KH * d->KW * d->Cin * d->Cout;
     const size_t need = (size_t)p.grid * part_stride(d) * sizeof(float);
     if (!ws || ws_bytes < need)
         return fail(SRX_ERR_WORKSPACE, "bwd_filter needs %zu workspace bytes, got %zu", need, ws_bytes);
@@ -389,9 +388,30 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
                     p.nch);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
-    err = launch_reduce_partials(a.part, wgrid, a.part_stride, (int)wn, d->Cout, dw, dbias, w_for_decay, wd_scale, s);
+    *n_partials = wgrid;
+    return SRX_OK;
+}
+
+int srx_conv2d_bwd_filter_reduce(const srx_conv_desc* d, const void* ws, int n_partials, float* dw, float* dbias,
+                                 const float* w_for_decay, float wd_scale, srx_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!ws || !dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (n_partials <= 0 || n_partials > kMaxGrid) return fail(SRX_ERR_BAD_ARG, "bad partial count %d", n_partials);
+    const size_t wn = (size_t)d->KH * d->KW * d->Cin * d->Cout;
+    hipError_t err = launch_reduce_partials((const float*)ws, n_partials, (int)part_stride(d), (int)wn, d->Cout, dw, dbias,
+                                            w_for_decay, wd_scale, (hipStream_t)stream);
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "reduce launch failed: %s", hipGetErrorString(err));
     return SRX_OK;
+}
+
+int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* dpre, float* dw, float* dbias,
+                          const float* w_for_decay, float wd_scale, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    if (!dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    int n = 0;
+    const int rc = srx_conv2d_bwd_filter_partials(d, x, dpre, ws, ws_bytes, &n, stream);
+    if (rc) return rc;
+    return srx_conv2d_bwd_filter_reduce(d, ws, n, dw, dbias, w_for_decay, wd_scale, stream);
 }
 
 #define SRX_CHECK_LAUNCH(expr, what)                                                         \

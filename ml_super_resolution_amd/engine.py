@@ -82,6 +82,8 @@ class ConvStack(object):
         self._decay_mask = None
         self._side = None
         self.overlap_wgrad = os.environ.get('SRX_OVERLAP_WGRAD', '0') != '0'   # wgrads on a side stream (see loss_and_backward; measured 1 % slower: off)
+        self.overlap_reduce = os.environ.get('SRX_OVERLAP_REDUCE', '0') != '0'  # partial-filter reductions on a side stream (see loss_and_backward)
+        self._ws2 = None
 
     # ---- parameter views -------------------------------------------------------------------
     def kernel(self, i, buf=None):
@@ -192,10 +194,38 @@ class ConvStack(object):
         two = self.overlap_wgrad and main is not None
         if two and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+        # SRX_OVERLAP_REDUCE=1: only the HBM-bound reduction of the per-workgroup partial filters (9 us per layer)
+        # goes to the side stream, where it could run under the next MFMA-bound dgrad; two workspaces alternate.
+        # Measured on MI355X (two A/B pairs): 14.16-14.19 ms per step against 14.04-14.11 ms in one stream -- the
+        # reduction does not hide (the dgrad's one persistent workgroup per CU leaves it no registers to run beside)
+        # and the cross-stream waits cost more than the 160 us at stake.  Off by default.
+        red = self.overlap_reduce and main is not None and not two
+        if red:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            if self._ws2 is None:
+                self._ws2 = torch.empty_like(self._ws)
+        ws_free = [None, None]   # event: the reduction reading workspace k has finished
         read_done = {}       # id of a rotating buffer -> event: the wgrad reading it has finished
         for i in range(last, -1, -1):
             s = self.specs[i]
-            if two:
+            if red:
+                k = i & 1
+                ws = self._ws if k == 0 else self._ws2
+                if ws_free[k] is not None:
+                    main.wait_event(ws_free[k])
+                n_part = ops.conv2d_bwd_filter_partials(acts[i], dpre, s.kernel_shape, s.padding, ws)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ready)
+                    ops.conv2d_bwd_filter_reduce(acts[i].shape, s.kernel_shape, s.padding, ws, n_part,
+                                                 self.kernel(i, self.grads), self.bias(i, self.grads),
+                                                 w_for_decay=self.kernel(i) if self.weight_decay else None,
+                                                 wd_scale=self.weight_decay)
+                    ws_free[k] = torch.cuda.Event()
+                    ws_free[k].record(self._side)
+            elif two:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(self._side):
@@ -219,7 +249,7 @@ class ConvStack(object):
                     main.wait_event(read_done.pop(out.data_ptr()))
                 dpre = ops.conv2d_bwd_data(dpre, self.kernel(i), acts[i].shape, s.padding,
                                            x_in=acts[i] if prev_act is not None else None, in_act=prev_act, out=out)
-        if two:
+        if two or red:
             main.wait_stream(self._side)
         if self.grad_hook is not None:
             self.grad_hook(self.grads)

@@ -107,6 +107,25 @@ def conv2d_bwd_filter(x, dpre, w_shape, padding='same', w_for_decay=None, wd_sca
     return dw, dbias
 
 
+def conv2d_bwd_filter_partials(x, dpre, w_shape, padding, workspace):
+    """First half of conv2d_bwd_filter: per-workgroup partial filters into `workspace`; returns their count."""
+    _chk(x, 'x'); _chk(dpre, 'dpre'); _chk(workspace, 'workspace')
+    d = conv_desc(x.shape, w_shape, padding)
+    n = ctypes.c_int(0)
+    check(lib().srx_conv2d_bwd_filter_partials(ctypes.byref(d), _ptr(x), _ptr(dpre), _ptr(workspace), workspace.numel() * 4,
+                                               ctypes.byref(n), _stream()), 'srx_conv2d_bwd_filter_partials')
+    return n.value
+
+
+def conv2d_bwd_filter_reduce(x_shape, w_shape, padding, workspace, n_partials, dw, dbias=None, w_for_decay=None, wd_scale=0.0):
+    """Second half: sums the partials into dw / dbias on the CURRENT stream (the caller orders it after the first half)."""
+    _chk(workspace, 'workspace'); _chk(dw, 'dw')
+    d = conv_desc(x_shape, w_shape, padding)
+    check(lib().srx_conv2d_bwd_filter_reduce(ctypes.byref(d), _ptr(workspace), int(n_partials), _ptr(dw), _ptr(dbias),
+                                             _ptr(w_for_decay), float(wd_scale), _stream()), 'srx_conv2d_bwd_filter_reduce')
+    return dw, dbias
+
+
 def act_bwd(dy, y, act, out=None):
     _chk(dy, 'dy'); _chk(y, 'y')
     out = out if out is not None else torch.empty_like(dy)

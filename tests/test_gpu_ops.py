@@ -318,3 +318,23 @@ def test_upsample_bwd_and_add_relu_grad(ops):
         np.testing.assert_array_equal(got, np.where(y > 0, a + b, np.float32(0)))
     with pytest.raises(ValueError):
         ops.upsample_nearest_bwd(dev(np.zeros((1, 5, 4, 3), np.float32)), 2)
+
+
+def test_bwd_filter_in_two_calls_is_the_same(ops):
+    """srx_conv2d_bwd_filter == srx_conv2d_bwd_filter_partials + srx_conv2d_bwd_filter_reduce, bit for bit (the
+    split lets a caller run the reduction on another stream)."""
+    rng = np.random.default_rng(90)
+    for shape, wshape, pad in (((3, 41, 41, 64), (3, 3, 64, 64), 'same'), ((2, 20, 70, 64), (3, 3, 64, 64), 'same'),
+                               ((2, 17, 17, 3), (5, 5, 3, 64), 'same'), ((2, 30, 30, 64), (3, 3, 64, 3), 'valid')):
+        x = dev(rng.uniform(-1, 1, shape).astype(np.float32))
+        k = wshape[0]
+        oshape = shape[:3] + (wshape[3],) if pad == 'same' else (shape[0], shape[1] - k + 1, shape[2] - k + 1, wshape[3])
+        dpre = dev(rng.normal(0, 1, oshape).astype(np.float32))
+        w = dev(rng.normal(0, 0.1, wshape).astype(np.float32))
+        dw, db = ops.conv2d_bwd_filter(x, dpre, wshape, pad, w_for_decay=w, wd_scale=1e-4)
+        ws = torch.empty((ops.bwd_filter_workspace_bytes(x.shape, wshape, pad) + 3) // 4, device='cuda')
+        n = ops.conv2d_bwd_filter_partials(x, dpre, wshape, pad, ws)
+        assert n >= 1
+        dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+        ops.conv2d_bwd_filter_reduce(x.shape, wshape, pad, ws, n, dw2, db2, w_for_decay=w, wd_scale=1e-4)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)

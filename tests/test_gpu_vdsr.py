@@ -112,6 +112,17 @@ def test_kernel_families_agree_bit_for_bit():
             _lib.lib().srx_set_conv_path(old)
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+    # the two optional stream arrangements of the backward pass (wgrads / partial reductions on a side stream) only
+    # reorder launches: same gradient bits
+    for attr in ('overlap_wgrad', 'overlap_reduce'):
+        setattr(m.stack, attr, True)
+        try:
+            m.stack.forward(sd, keep=True)
+            m.stack.loss_and_backward(hd)
+            torch.cuda.synchronize()
+            assert torch.equal(m.stack.grads, outs[1][1]), attr
+        finally:
+            setattr(m.stack, attr, False)
 
 
 def test_full_size_batch_properties():
