@@ -65,10 +65,11 @@ const char* srx_version(void);
 const char* srx_last_error(void);
 
 /* Selects the forward / dgrad kernel family for layers with >= 16 input channels:
- *   1 (default)  3x3 body layers (16..64 exact-fit input channels, full-width tiles, none / ReLU /
- *                ReluGrad / residual epilogues) run on one workgroup per CU with a double-buffered LDS
- *                tile, everything but the MFMAs done by scalar and memory instructions; all other shapes
- *                use the kernels of path 0;
+ *   1 (default)  3x3 body layers (16..64 exact-fit input channels, none / ReLU / ReluGrad / residual
+ *                epilogues; full-width tiles, or column strips for 64 -> 64 layers of images too wide
+ *                for them) run on one workgroup per CU with a double-buffered LDS tile, everything but
+ *                the MFMAs done by scalar and memory instructions; all other shapes use the kernels of
+ *                path 0;
  *   0            two persistent workgroups per CU, one LDS tile each, for every shape.
  * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
 int srx_set_conv_path(int pipelined);

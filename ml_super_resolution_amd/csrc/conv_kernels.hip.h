@@ -12,12 +12,15 @@
 //    Activation / residual add / upstream activation-gradient mask are fused in the epilogue.
 //      - conv_pipe_kernel (the 3x3 body layers): one workgroup per CU, weights in AGPRs, the tile
 //        double-buffered, everything that is not an MFMA done by scalar and memory instructions;
+//        conv_pipe_strip_kernel: the same on column strips, for images too wide for full-width tiles;
 //      - conv_mfma_kernel / conv_mfma_generic_kernel (all other shapes): two workgroups per CU that stage
-//        between their MFMA phases.
+//        between their MFMA phases;
+//      - the 64 <-> 3 channel layers have plain-FMA kernels of their own in conv_narrow.hip.
 //  * wgrad: the dW accumulators (144 VGPRs for 3x3x64 per 16 Cout) are stationary for the whole kernel;
 //    x comes from the same LDS halo tile, dpre straight from global (each element is used by exactly one
-//    wave).  Per-workgroup partials are reduced by a second, fixed-order kernel.  wgrad_lin_kernel walks
-//    the padded tile positions (VALU-free K loop), wgrad_mfma_kernel the real pixels with per-lane cursors.
+//    wave).  Per-workgroup partials are reduced by a second, fixed-order kernel.  wgrad_pipe_kernel /
+//    wgrad_lin_kernel walk the padded tile positions (VALU-free K loop; one double-buffered workgroup per CU /
+//    two workgroups per CU), wgrad_mfma_kernel the real pixels with per-lane cursors.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
