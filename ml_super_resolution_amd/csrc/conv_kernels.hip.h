@@ -702,6 +702,8 @@ struct StageGeo {      // wave-uniform constants of the staging sequence
     int rowfix_g, rowfix_l;  // extra bytes (beyond the constant pass step) when the next pass starts a new row: image, LDS
     unsigned long long m_first, m_last;   // EXEC masks of a row's first / last pass (pad columns / row end)
     unsigned long long m_row;             // column-strip tiles only: lanes of a row's last pass that lie inside the tile row
+    unsigned long long m_mid;             // strips whose invalid columns may start before the last pass (wgrad's narrow
+                                          // last strip): valid lanes of the passes between the first and the last
 };
 // The scalar offset is UNSIGNED to the hardware (measured: a negative one puts the whole pass out of range),
 // so the buffer resource starts pad_l pixels before the image (those bytes are never touched: the lanes
@@ -766,8 +768,21 @@ __device__ __forceinline__ f32x4 stage_fire(unsigned long long m, int so, __amdg
 // image, the edge-halo lanes with an out-of-range scalar offset (they return 0); one LDS write covers both.
 // m_first / m_last are then the VALID lanes of a row's first / last pass for the strip being staged (set per
 // tile), m_row the lanes inside the tile row.
+template <bool MID = false>
 __device__ __forceinline__ void stage_mask_az(const StageSeq& q, const StageGeo& G, unsigned long long& m, unsigned long long& t,
                                               unsigned long long& r) {
+    if constexpr (MID) {
+        // three classes of passes: first (m_first, already combined with m_last when a row is one pass), last, between
+        asm volatile("s_cmp_eq_u32 %3, %4\n\t"
+                     "s_cselect_b64 %1, %6, %8\n\t"
+                     "s_cselect_b64 %2, %7, -1\n\t"
+                     "s_cmp_eq_u32 %3, 0\n\t"
+                     "s_cselect_b64 %0, %5, %1\n\t"
+                     "s_mov_b64 %1, -1"
+                     : "=&s"(m), "=&s"(t), "=&s"(r)
+                     : "s"(q.j), "s"(G.JP1), "s"(G.m_first), "s"(G.m_last), "s"(G.m_row), "s"(G.m_mid) : "scc");
+        return;
+    }
     asm volatile("s_cmp_eq_u32 %3, 0\n\t"
                  "s_cselect_b64 %0, %5, -1\n\t"
                  "s_cmp_eq_u32 %3, %4\n\t"
@@ -854,7 +869,7 @@ __device__ __forceinline__ void stage_pass_now(StageSeq& qi, StageSeq& qc, const
 }
 
 // a whole tile with NB loads in flight (kernels that stage between their MFMA phases)
-template <int CINP, int NB, bool Z = false>
+template <int CINP, int NB, bool Z = false, bool MID = false>
 __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, const StageGeo& G, __amdgpu_buffer_rsrc_t rsrc,
                                                   int voff_lane, int wl_lane) {
     constexpr int PPP = 256 / (CINP / 4);
@@ -867,7 +882,7 @@ __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, co
             int so;
             if constexpr (Z) {
                 unsigned long long m;
-                stage_mask_az(qi, G, m, t, mk[i]);
+                stage_mask_az<MID>(qi, G, m, t, mk[i]);
                 stage_mask_bz(qi, m, t, mk[i], so);
                 v[i] = stage_fire_z(m, mk[i], so, rsrc, voff_lane);
             } else {
@@ -1714,8 +1729,12 @@ __device__ __forceinline__ float dpre_step_now(DpreSeq& q, const DpreGeo& D, __a
     return b;
 }
 
-template <int KH, int KW, int CINP, int NCH, int MINW>
-__global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a) {
+// Z = true: column strips (images too wide for full-width tiles).  Strips are disjoint (the last one of an image
+// may be narrower); the x tile is staged with the strip variant of the scalar stager (edge halo columns loaded as
+// zeros), the dpre walk only needs the strip's width as the number of real positions per tile row and the image's
+// row pitch in the row-wrap correction (which then has the other sign: a tile row is shorter than an image row).
+template <int KH, int KW, int CINP, int NCH, int MINW, bool Z>
+__device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PS = Lds<CINP>::PS;
     constexpr int TAPS = KH * KW;
@@ -1760,7 +1779,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
         for (int i = tid; i < n16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
     }
     // scalar staging (see conv_pipe_kernel) when the channels fit exactly, else the generic stager
-    const bool lean = (a.Cin == CINP) && (a.RS >= PPP);
+    const bool lean = Z || ((a.Cin == CINP) && (a.RS >= PPP));   // (the host sends strips only when this holds)
     const int voff_lane = tid * 16;
     const int wl_lane = (sp * PS + 4 * c4) * 4;
     StageGeo SG;
@@ -1770,15 +1789,20 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     SG.rowfix_l = __builtin_amdgcn_readfirstlane((a.RS - JP * PPP) * PS * 4);
     SG.m_first = uniform64(__ballot(sp >= a.pad_l));
     SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
+    SG.m_row = SG.m_last;
+    SG.m_mid = ~0ull;
     DpreGeo DG;
-    DG.tw = __builtin_amdgcn_readfirstlane(a.OW);
+    DG.tw = __builtin_amdgcn_readfirstlane(Z ? a.TW : a.OW);
     DG.RS = __builtin_amdgcn_readfirstlane(a.RS);
-    DG.padb = __builtin_amdgcn_readfirstlane((a.RS - a.OW) * a.Cout * 4);
+    // row-wrap correction: a tile row has RS positions, an image row OW pixels (negative for strips)
+    const int padb = (a.RS - a.OW) * a.Cout * 4;
+    DG.padb = __builtin_amdgcn_readfirstlane(padb);
     DG.stepb = __builtin_amdgcn_readfirstlane(16 * a.Cout);
-    // lane offsets count from RS-OW pixels BEFORE the unit's first pixel (the buffer resource starts there; those
+    // lane offsets count from `bias_b` bytes BEFORE the unit's first pixel (the buffer resource starts there; those
     // bytes are never touched), so that both variants are non-negative: offsets are unsigned to the hardware
-    const int voff_bn = (kq * a.Cout + co_c) * 4;                    // lane whose position lies in the next tile row
-    const int voff_b = voff_bn + (a.RS - a.OW) * a.Cout * 4;         // lane in the row of the step's first position
+    const int bias_b = padb > 0 ? padb : 0;
+    const int voff_b = (kq * a.Cout + co_c) * 4 + bias_b;            // lane in the row of the step's first position
+    const int voff_bn = voff_b - padb;                               // lane whose position lies in the next tile row
 
     f32x4 acc[QW][4];
 #pragma unroll
@@ -1794,7 +1818,14 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     int u = u0;
     while (u < u1) {
         const int h = u % a.OH;
-        const int n = u / a.OH;
+        int n = u / a.OH;
+        int ow0 = 0, tw = a.OW;
+        if constexpr (Z) {
+            const int tx = n % a.NTX;
+            n = n / a.NTX;
+            ow0 = tx * a.TW;
+            tw = a.OW - ow0 < a.TW ? a.OW - ow0 : a.TW;
+        }
         int th = a.TH;
         if (a.OH - h < th) th = a.OH - h;
         if (u1 - u < th) th = u1 - u;
@@ -1805,14 +1836,25 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
             const int left = __builtin_amdgcn_readfirstlane((th + KH - 1) * JP);
             const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;
             qi.j = 0; qc.j = 0;
-            qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+            qi.off = __builtin_amdgcn_readfirstlane(((h - a.pad_t) * a.W + ow0) * CINP * 4);
             qc.off = 0;
+            if constexpr (Z) {
+                // image column of tile slot c is ow0 - pad_l + c; a narrow last strip has invalid columns before the
+                // last pass too (the host keeps a tile row to at most three passes: first / between / last)
+                const int iw0 = ow0 - a.pad_l + sp;
+                const unsigned long long v0 = __ballot(iw0 >= 0 && iw0 < a.W && sp < a.RS);
+                const int cl = (JP - 1) * PPP + sp;
+                const unsigned long long vl = __ballot(cl < a.RS && iw0 + (JP - 1) * PPP >= 0 && iw0 + (JP - 1) * PPP < a.W);
+                SG.m_first = uniform64(JP == 1 ? (v0 & vl) : v0);
+                SG.m_last = uniform64(vl);
+                SG.m_mid = uniform64(__ballot(iw0 + PPP >= 0 && iw0 + PPP < a.W));
+            }
             qi.left = left; qc.left = left;
             qi.thr = __builtin_amdgcn_readfirstlane(left - above);
             qc.thr = 0;
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
-            stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
+            stage_tile_scalar<CINP, 6, Z, Z>(qi, qc, SG, xrs, voff_lane, wl_lane);
         } else {
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, -a.pad_l, a.RS, a.inv_rs,
                              (th + KH - 1) * a.RS + (KW - 1), tid);
@@ -1820,13 +1862,16 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
         lds_barrier();
 
         const int nsteps = (th * a.RS + 3) >> 2;
+        // the unit's pixels: th rows, the last one ending after its tw real positions
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.dpre) + (((size_t)n * a.OH + h) * a.OW - (a.RS - a.OW)) * a.Cout, 0,
-            (th * a.OW + (a.RS - a.OW)) * a.Cout * 4, 0x00020000);
+            reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(a.dpre) + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout) - bias_b), 0,
+            ((th - 1) * a.OW + tw) * a.Cout * 4 + bias_b, 0x00020000);
+        const int tw_u = __builtin_amdgcn_readfirstlane(tw);
         DpreSeq dq;
         dq.c0 = __builtin_amdgcn_readfirstlane(0);
         dq.soff = __builtin_amdgcn_readfirstlane(0);
         float bq[4];
+        DG.tw = tw_u;
 #pragma unroll
         for (int j = 0; j < PF; ++j) bq[j] = dpre_step_now(dq, DG, brs, voff_b, voff_bn);
         bq[3] = 0.f;
@@ -1857,7 +1902,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
 #pragma unroll
                         for (int pc = 0; pc < 6; ++pc) {
                             if ((pc * QW) / 6 != k) continue;
-                            if (pc == 0) dpre_counts(dq, DG.tw, DG.RS, nA, nAF);
+                            if (pc == 0) dpre_counts(dq, tw_u, DG.RS, nA, nAF);
                             if (pc == 1) mA = low_groups_mask(nA);
                             if (pc == 2) mAF = low_groups_mask(nAF);
                             if (pc == 3) dpre_masks(mA, mAF, mF, mB);
@@ -1894,6 +1939,15 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
     if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
+}
+
+template <int KH, int KW, int CINP, int NCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a) {
+    wgrad_lin_body<KH, KW, CINP, NCH, MINW, false>(a);
+}
+template <int KH, int KW, int CINP, int NCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_lin_strip_kernel(const WgradArgs a) {
+    wgrad_lin_body<KH, KW, CINP, NCH, MINW, true>(a);
 }
 
 

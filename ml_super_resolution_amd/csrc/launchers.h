@@ -23,6 +23,7 @@ bool launch_pipe_strip(const ConvKey& k, const ConvArgs& a, int grid, size_t lds
 bool launch_conv_generic(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_wgrad_lin_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_pipe(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 
 hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
@@ -90,6 +91,11 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
 #define SRX_WGRAD_LIN_CASE(KH, KW, CINP, NCH, MINW)                                                       \
     if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH) {                                     \
         *err = launch_with_lds(wgrad_lin_kernel<KH, KW, CINP, NCH, MINW>, a, grid, lds, s);               \
+        return true;                                                                                      \
+    }
+#define SRX_WGRAD_LIN_STRIP_CASE(KH, KW, CINP, NCH, MINW)                                                 \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH) {                                     \
+        *err = launch_with_lds(wgrad_lin_strip_kernel<KH, KW, CINP, NCH, MINW>, a, grid, lds, s);         \
         return true;                                                                                      \
     }
 #define SRX_WGRAD_PIPE_CASE(KH, KW, CINP, NCH)                                                            \

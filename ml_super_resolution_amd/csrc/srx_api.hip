@@ -382,7 +382,14 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
         if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
         if (!wdone && use_narrow) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
     }
+    // column strips: exact-fit channels and a tile row of at least one staging pass (the strip stager is the scalar one)
+    // (and every strip, the narrower last one included, at least one 4-position step wide: the lanes of a step that
+    // fall into the next tile row are taken to be real positions)
+    const bool lin_strip_ok = use_lin && p.NTX > 1 && d->Cin == p.cinp && p.RS >= wppp && p.TW >= 4 && lin_lds <= 80 * 1024 &&
+                              (OW % p.TW == 0 || OW % p.TW >= 4) && p.RS <= 3 * wppp &&
+                              (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096 && (long)OH * OW * d->Cout * 4 < (1L << 30);
     if (wdone) {
+    } else if (lin_strip_ok && launch_wgrad_lin_strip(k, a, p.grid, lin_lds, s, &err)) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
     } else if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
         return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,

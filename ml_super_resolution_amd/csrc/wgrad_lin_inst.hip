@@ -10,4 +10,9 @@ bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds
     SRX_WGRAD_LIN_CASE(3, 3, 32, 1, 2)
     return false;
 }
+// column strips (wide images): the 64 -> 64 body layers
+bool launch_wgrad_lin_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
+    SRX_WGRAD_LIN_STRIP_CASE(3, 3, 64, 4, 2)
+    return false;
+}
 }  // namespace srx

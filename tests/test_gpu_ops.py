@@ -94,6 +94,8 @@ SHAPES = [
     (1, 9, 61, 3, 64, 64, 'SAME', None),
     (1, 12, 80, 3, 64, 64, 'VALID', 'relu'),
     (5, 4, 203, 3, 64, 64, 'SAME', 'relu'),
+    (2, 13, 65, 3, 64, 64, 'SAME', None),        # last strip 1 column wide (the strip wgrad must decline it)
+    (3, 21, 100, 3, 64, 64, 'SAME', 'relu'),     # last strip 4 columns wide
     # the 16-lanes-per-position kernels of the 64 <-> 3 channel layers (conv_narrow.hip): rows shorter than one
     # 16-position step, VALID geometry, a 1x1 image, a wide image, many positions per workgroup
     (3, 6, 9, 3, 64, 3, 'VALID', 'tanh'),
