@@ -33,12 +33,25 @@ class EnetGenerator(object):
     def __init__(self, device='cuda', seed=None):
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
-        self.kernels, self.biases = [], []
+        # all variables in ONE flat buffer (16-byte aligned slices), gradients in a second one of the same layout:
+        # the Adam update of the 50 tensors is a single launch
+        shapes, off = [], 0
         for k, cin, cout in generator_layers():
-            w = torch.empty((k, k, cin, cout), dtype=torch.float32, device=self.device)
-            truncated_normal_(w, 0.02, gen)                               # model_enet.py:10,46
-            self.kernels.append(w)
-            self.biases.append(torch.zeros(cout, dtype=torch.float32, device=self.device))
+            for shape in ((k, k, cin, cout), (cout,)):
+                n = 1
+                for d in shape:
+                    n *= d
+                shapes.append((off, n, shape))
+                off += (n + 3) // 4 * 4
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        view = lambda buf, j: buf[shapes[j][0]:shapes[j][0] + shapes[j][1]].view(shapes[j][2])
+        self.kernels = [view(self.params, 2 * i) for i in range(len(shapes) // 2)]
+        self.biases = [view(self.params, 2 * i + 1) for i in range(len(shapes) // 2)]
+        self._gk = [view(self.grads, 2 * i) for i in range(len(shapes) // 2)]
+        self._gb = [view(self.grads, 2 * i + 1) for i in range(len(shapes) // 2)]
+        for w in self.kernels:
+            truncated_normal_(w, 0.02, gen)                               # model_enet.py:10,46 (biases: zeros)
         self.placeholders = {}
         self._saved = None
 
@@ -99,7 +112,7 @@ class EnetGenerator(object):
         grads = [None] * len(K)
 
         def wgrad(i, dpre):
-            grads[i] = ops.conv2d_bwd_filter(ins[i], dpre, K[i].shape, 'same')
+            grads[i] = ops.conv2d_bwd_filter(ins[i], dpre, K[i].shape, 'same', dw=self._gk[i], dbias=self._gb[i])
 
         i = len(K) - 1                           # 24: 64 -> 3, no activation
         g = d_sr.contiguous()
@@ -125,15 +138,19 @@ class EnetGenerator(object):
 
     def adam_step(self, grads, state, lr=1e-4):
         """tf.train.AdamOptimizer(learning_rate=0.0001) on the g_ variables (model_enet.py:336-337); `state` is a
-        dict this method fills on first use (slots m, v and the step count)."""
+        dict this method fills on first use (slots m, v and the step count).  `grads` as returned by backward()
+        (views of self.grads: nothing to copy) or any list of (dkernel, dbias)."""
         if not state:
             state['t'] = 0
-            state['m'] = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in zip(self.kernels, self.biases)]
-            state['v'] = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in zip(self.kernels, self.biases)]
-        state['t'] += 1
+            state['m'] = torch.zeros_like(self.params)
+            state['v'] = torch.zeros_like(self.params)
         for i, (dw, db) in enumerate(grads):
-            ops.adam_tf_step(self.kernels[i], dw, state['m'][i][0], state['v'][i][0], lr, state['t'])
-            ops.adam_tf_step(self.biases[i], db, state['m'][i][1], state['v'][i][1], lr, state['t'])
+            if dw.data_ptr() != self._gk[i].data_ptr():
+                self._gk[i].copy_(dw)
+            if db.data_ptr() != self._gb[i].data_ptr():
+                self._gb[i].copy_(db)
+        state['t'] += 1
+        ops.adam_tf_step(self.params, self.grads, state['m'], state['v'], lr, state['t'])
 
     def run(self, keys, feed_dict):
         feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}
