@@ -74,13 +74,32 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     }
     if (th_max > OH) th_max = OH;
     if (th_max > 16) th_max = 16;
-    // keep enough tiles in flight to occupy the chip on small problems
+    // Small problems (fewer than two tallest tiles per workgroup slot): the launch is latency-bound, so pick the tile
+    // height that minimises the time of the busiest workgroup instead of the tallest one.  Per tile a workgroup pays
+    // one staging round trip (load -> LDS -> barrier, epilogue: ~1.5 units) plus one unit (a 16-pixel sub-tile's MFMA
+    // chain over all taps, ~2 us for 3x3x64) per sub-tile its busiest wave owns.  Measured at 32x17x17, 64->32: one-row
+    // tiles (the previous rule) 35-39 us per launch.
     const long rows_total = (long)N * NTX * OH;
-    while (th_max > 1 && rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) th_max -= 1;
+    bool small = false;
+    if (rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) {
+        const int npart = 4 / p->nch;
+        double best_cost = 1e30;
+        int best_th = 1;
+        for (int th = 1; th <= (int)th_max; ++th) {
+            const long tiles = (long)N * NTX * ((OH + th - 1) / th);
+            const long slots = tiles < kMaxGrid ? tiles : kMaxGrid;
+            const long per_wg = (tiles + slots - 1) / slots;
+            const long sub = ((long)th * TW + 15) / 16;
+            const double cost = (double)per_wg * (1.5 + (double)((sub + npart - 1) / npart));
+            if (cost <= best_cost + 1e-9) { best_cost = cost; best_th = th; }   // ties: the taller tile (less halo)
+        }
+        th_max = best_th;
+        small = true;
+    }
     // among the tallest candidates pick the one wasting the fewest lanes of the 16-pixel sub-tiles
     int best = (int)th_max;
     double best_eff = 0.0;
-    for (int th = (int)th_max; th >= (int)((th_max + 1) / 2) && th >= 1; --th) {
+    for (int th = (int)th_max; !small && th >= (int)((th_max + 1) / 2) && th >= 1; --th) {
         const int px = th * TW;
         const double eff = (double)px / (16.0 * ((px + 15) / 16));
         if (eff > best_eff + 1e-9) { best_eff = eff; best = th; }
@@ -88,6 +107,9 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     p->TH = best; p->TW = TW; p->NTX = NTX; p->RS = RS;
     p->units_total = (int)rows_total;
     long g = rows_total / p->TH;
+    // (small problems: one workgroup per tile -- with tiles-per-image workgroups per image the static row split falls
+    // on image boundaries, so no workgroup straddles two images and pays for two tiles)
+    if (small) g = (long)N * NTX * ((OH + p->TH - 1) / p->TH);
     if (g < 1) g = 1;
     p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
     {
