@@ -81,7 +81,7 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     // tiles (the previous rule) 35-39 us per launch.
     const long rows_total = (long)N * NTX * OH;
     bool small = false;
-    if (rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) {
+    if (rows_total / th_max < 2 * kMaxGrid) {
         const int npart = 4 / p->nch;
         double best_cost = 1e30;
         int best_th = 1;
