@@ -81,7 +81,11 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     // tiles (the previous rule) 35-39 us per launch.
     const long rows_total = (long)N * NTX * OH;
     bool small = false;
-    if (rows_total / th_max < 2 * kMaxGrid) {
+    static int small_rule = -1;
+    if (small_rule < 0) { const char* e = getenv("SRX_SMALL_RULE"); small_rule = e ? atoi(e) : 1; }   // 0: tallest tile that leaves two per slot (A/B)
+    if (!small_rule) {
+        while (th_max > 1 && rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) th_max -= 1;
+    } else if (rows_total / th_max < 2 * kMaxGrid) {
         const int npart = 4 / p->nch;
         double best_cost = 1e30;
         int best_th = 1;
