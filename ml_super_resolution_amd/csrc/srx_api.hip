@@ -44,8 +44,10 @@ int chunks_for(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : (c <= 64 ? 4 : -1));
 
 // in_c / out_c: channels of the tensor staged through LDS / produced by the kernel.
 // (H,W) staged tensor dims, (OH,OW) produced tensor dims, pads relative to the staged tensor.
+// lean_epilogue: the launch carries one of the epilogues the one-workgroup-per-CU kernels implement (none / ReLU;
+// every dgrad and wgrad) -- only used to tell which kernel family the plan is for.
 int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, int KW, int pad_t, int pad_l,
-              Plan* p) {
+              Plan* p, bool lean_epilogue = true) {
     p->KH = KH; p->KW = KW;
     p->cinp = pad_channels(in_c);
     p->nch = chunks_for(out_c);
@@ -74,17 +76,25 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     }
     if (th_max > OH) th_max = OH;
     if (th_max > 16) th_max = 16;
+    const long th_fit = th_max;
     // Small problems (fewer than two tallest tiles per workgroup slot): the launch is latency-bound, so pick the tile
     // height that minimises the time of the busiest workgroup instead of the tallest one.  Per tile a workgroup pays
     // one staging round trip (load -> LDS -> barrier, epilogue: ~1.5 units) plus one unit (a 16-pixel sub-tile's MFMA
     // chain over all taps, ~2 us for 3x3x64) per sub-tile its busiest wave owns.  Measured at 32x17x17, 64->32: one-row
     // tiles (the previous rule) 35-39 us per launch.
     const long rows_total = (long)N * NTX * OH;
-    bool small = false;
+    bool small = false, rows_split = false;
     static int small_rule = -1;
     if (small_rule < 0) { const char* e = getenv("SRX_SMALL_RULE"); small_rule = e ? atoi(e) : 1; }   // 0: tallest tile that leaves two per slot (A/B)
     if (!small_rule) {
         while (th_max > 1 && rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) th_max -= 1;
+    } else if (rows_total / th_max < 2 * kMaxGrid && KH == 3 && KW == 3 && p->cinp >= 16 && in_c == p->cinp && lean_epilogue &&
+               (out_c & 3) == 0 && RS >= 256 / (p->cinp / 4) && (NTX > 1 ? p->nch == 4 : 16 * (4 / p->nch) <= OW)) {
+        // ... except for the layers the one-workgroup-per-CU kernels take (3x3, exact-fit channels): they stage the next
+        // tile under the running one and pay per group, not per tile, so the tallest tile stays best (measured at
+        // 64x41x41: 4.57 ms per train step with 5-row tiles, 4.85 with 3, 5.15 with 2); only the row split must
+        // still reach every CU.
+        rows_split = true;
     } else if (rows_total / th_max < 2 * kMaxGrid) {
         const int npart = 4 / p->nch;
         double best_cost = 1e30;
@@ -108,12 +118,18 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
         const double eff = (double)px / (16.0 * ((px + 15) / 16));
         if (eff > best_eff + 1e-9) { best_eff = eff; best = th; }
     }
+    {
+        static int th_env = -2;     // SRX_TH: force the tile height (tuning experiments; clamped to what fits)
+        if (th_env == -2) { const char* e = getenv("SRX_TH"); th_env = e ? atoi(e) : -1; }
+        if (th_env > 0) best = th_env < th_fit ? th_env : (int)th_fit;
+    }
     p->TH = best; p->TW = TW; p->NTX = NTX; p->RS = RS;
     p->units_total = (int)rows_total;
     long g = rows_total / p->TH;
     // (small problems: one workgroup per tile -- with tiles-per-image workgroups per image the static row split falls
     // on image boundaries, so no workgroup straddles two images and pays for two tiles)
     if (small) g = (long)N * NTX * ((OH + p->TH - 1) / p->TH);
+    if (rows_split) g = rows_total;
     if (g < 1) g = 1;
     p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
     {
@@ -305,7 +321,8 @@ int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
-    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
+    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p,
+                   d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU);
     if (rc) return rc;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
