@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
     const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
     const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
     if (a.stagger) stagger_second_workgroup(a.stagger);
-    unsigned long long t_mfma = 0, t_stage = 0, t_bar1 = 0, t_load = 0, t_pro = 0, t_epi = 0;
-    const unsigned long long t_begin = SRX_STAMP();
+    [[maybe_unused]] unsigned long long t_mfma = 0, t_stage = 0, t_bar1 = 0, t_load = 0, t_pro = 0, t_epi = 0;   // (trace builds)
+    [[maybe_unused]] const unsigned long long t_begin = SRX_STAMP();
     // Work distribution.  Static: a contiguous range of output rows per workgroup.  Dynamic (tile_counter
     // set): fixed tiles of TH rows handed out through one atomic counter -- the wave that an fp32-MFMA
     // partner starves falls behind, and a static split then leaves one workgroup per CU idle at the end.
@@ -1262,7 +1262,7 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
     unsigned long long tt[4] = {0, 0, 0, 0};   // trace: unit prologue, group sections, -, drain+barrier
     int n, h, th, ow0;
     tile_of(u0, n, h, th, ow0);
-    const unsigned long long t_begin = SRX_STAMP();
+    [[maybe_unused]] const unsigned long long t_begin = SRX_STAMP();
     __syncthreads();     // (set-up writes above vs. the first tile's writes below touch different bytes; this orders them with the reads)
     {
         StageSeq qi, qc;
@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
         float t = wr[i];
         asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(wr[i]) : "v"(t));
     }
-    const unsigned long long t_first = SRX_STAMP();
+    [[maybe_unused]] const unsigned long long t_first = SRX_STAMP();
 
     PipePend<MAXG, AUX> pd;
 #pragma unroll
@@ -2135,8 +2135,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     int u = u0;
     int n, h, th;
     tile_of(u, n, h, th);
-    unsigned long long t_loop = 0, t_end = 0, t_full = 0;
-    const unsigned long long t_begin = SRX_STAMP();
+    [[maybe_unused]] unsigned long long t_loop = 0, t_end = 0, t_full = 0;   // (trace builds)
+    [[maybe_unused]] const unsigned long long t_begin = SRX_STAMP();
     __syncthreads();
     {
         StageSeq qi, qc;
