@@ -8,45 +8,55 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ml_super_resolution_amd import ops
 from oracle import oracle as O
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 LAYERS = [(3, 64, 64), (3, 64, 64), (3, 64, 64), (3, 64, 32), (3, 32, 32), (3, 64, 3), (3, 3, 64), (1, 64, 64), (3, 32, 27),
           (5, 3, 64), (5, 32, 3), (9, 3, 64), (3, 64, 48), (1, 64, 32)]
 ACTS = [None, 'relu', 'relu', 'tanh']
-dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-bad = 0
-for it in range(cases):
-    k, cin, cout = LAYERS[rng.integers(len(LAYERS))]
-    pad = 'SAME' if rng.random() < 0.7 else 'VALID'
-    act = ACTS[rng.integers(len(ACTS))]
-    big = rng.random() < 0.3
-    n = int(rng.integers(1, 4 if big else 9))
-    h = int(rng.integers(k if pad == 'VALID' else 1, 90 if big else 30))
-    w = int(rng.integers(k if pad == 'VALID' else 1, 140 if big else 30))
-    x = rng.uniform(-1, 1, (n, h, w, cin)).astype(np.float32)
-    wt = rng.normal(0, 1.0 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
-    b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
-    tag = 'N%d %dx%d k%d %d->%d %s %s' % (n, h, w, k, cin, cout, pad, act)
-    try:
-        y_ref = O.c_conv2d_fwd(x, wt, b, pad, act)
-        y = ops.conv2d_fwd(dev(x), dev(wt), dev(b), pad, act).cpu().numpy()
-        dpre = rng.normal(0, 1, y_ref.shape).astype(np.float32)
-        dx_ref = O.c_conv2d_bwd_data(dpre, wt, (h, w), pad)
-        xin = np.maximum(x, 0)
-        dx = ops.conv2d_bwd_data(dev(dpre), dev(wt), x.shape, pad, x_in=dev(xin), in_act='relu').cpu().numpy()
-        dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (k, k), pad)
-        dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), wt.shape, pad)
-        errs = []
-        for name, got, ref in (('y', y, y_ref), ('dx', dx, dx_ref * (xin > 0)), ('dw', dw.cpu().numpy(), dw_ref), ('db', db.cpu().numpy(), db_ref)):
-            scale = max(np.abs(ref).max(), 1e-30)
-            e = np.abs(got - ref).max() / scale
-            if not np.isfinite(got).all() or e > 1e-3:
-                errs.append('%s %.2e' % (name, e))
-        if errs:
-            bad += 1
-            print('FAIL', tag, errs, flush=True)
-    except Exception as exc:
-        bad += 1
-        print('ERROR', tag, repr(exc)[:200], flush=True)
-print('fuzz: %d cases, %d bad' % (cases, bad))
-sys.exit(1 if bad else 0)
+
+
+def run(cases, seed, verbose=True):
+    """Returns the list of failing case descriptions."""
+    rng = np.random.default_rng(seed)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    failures = []
+    for it in range(cases):
+        k, cin, cout = LAYERS[rng.integers(len(LAYERS))]
+        pad = 'SAME' if rng.random() < 0.7 else 'VALID'
+        act = ACTS[rng.integers(len(ACTS))]
+        big = rng.random() < 0.3
+        n = int(rng.integers(1, 4 if big else 9))
+        h = int(rng.integers(k if pad == 'VALID' else 1, 90 if big else 30))
+        w = int(rng.integers(k if pad == 'VALID' else 1, 140 if big else 30))
+        x = rng.uniform(-1, 1, (n, h, w, cin)).astype(np.float32)
+        wt = rng.normal(0, 1.0 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+        tag = 'N%d %dx%d k%d %d->%d %s %s' % (n, h, w, k, cin, cout, pad, act)
+        try:
+            y_ref = O.c_conv2d_fwd(x, wt, b, pad, act)
+            y = ops.conv2d_fwd(dev(x), dev(wt), dev(b), pad, act).cpu().numpy()
+            dpre = rng.normal(0, 1, y_ref.shape).astype(np.float32)
+            dx_ref = O.c_conv2d_bwd_data(dpre, wt, (h, w), pad)
+            xin = np.maximum(x, 0)
+            dx = ops.conv2d_bwd_data(dev(dpre), dev(wt), x.shape, pad, x_in=dev(xin), in_act='relu').cpu().numpy()
+            dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (k, k), pad)
+            dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), wt.shape, pad)
+            errs = []
+            for name, got, ref in (('y', y, y_ref), ('dx', dx, dx_ref * (xin > 0)), ('dw', dw.cpu().numpy(), dw_ref),
+                                   ('db', db.cpu().numpy(), db_ref)):
+                scale = max(np.abs(ref).max(), 1e-30)
+                e = np.abs(got - ref).max() / scale
+                if not np.isfinite(got).all() or e > 1e-3:
+                    errs.append('%s %.2e' % (name, e))
+            if errs:
+                failures.append('%s: %s' % (tag, errs))
+        except Exception as exc:
+            failures.append('%s: %r' % (tag, exc))
+        if verbose and failures and failures[-1].startswith(tag):
+            print('FAIL', failures[-1], flush=True)
+    return failures
+
+
+if __name__ == '__main__':
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad = run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print('fuzz: %d cases, %d bad' % (cases, len(bad)))
+    sys.exit(1 if bad else 0)
