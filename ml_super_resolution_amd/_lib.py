@@ -50,6 +50,10 @@ def lib():
         raise SrxError('libsrx.so not found at %s -- build it with `make -C %s` (or '
                        '__graft_entry__.build()); there is no CPU fallback' %
                        (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so, and the tensors handed to the library
+    # live in that runtime.  Loading libsrx.so first would bind it to the system copy instead, and its launches then
+    # fail with "no ROCm-capable device is detected" -- so torch's libraries are loaded before ours.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i, f = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float
     dp = ctypes.POINTER(ConvDesc)

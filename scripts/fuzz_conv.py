@@ -33,6 +33,13 @@ def run(cases, seed, verbose=True):
         try:
             y_ref = O.c_conv2d_fwd(x, wt, b, pad, act)
             y = ops.conv2d_fwd(dev(x), dev(wt), dev(b), pad, act).cpu().numpy()
+            if rng.random() < 0.35:      # residual operand (+ ReLU after the add)
+                skip = rng.uniform(-1, 1, y_ref.shape).astype(np.float32)
+                post = bool(rng.random() < 0.5)
+                ys_ref = O.c_conv2d_fwd(x, wt, b, pad, act, skip=skip, post_relu=post)
+                ys = ops.conv2d_fwd(dev(x), dev(wt), dev(b), pad, act, skip=dev(skip), post_add_relu=post).cpu().numpy()
+                if not np.isfinite(ys).all() or np.abs(ys - ys_ref).max() > 1e-3 * max(np.abs(ys_ref).max(), 1e-30):
+                    failures.append('%s: residual variant (post_relu=%s)' % (tag, post))
             dpre = rng.normal(0, 1, y_ref.shape).astype(np.float32)
             dx_ref = O.c_conv2d_bwd_data(dpre, wt, (h, w), pad)
             xin = np.maximum(x, 0)
