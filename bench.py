@@ -10,7 +10,17 @@ backward (19 dgrads + 20 wgrads), gradient all-reduce over RCCL when N > 1, TF-A
 `fwd_hr_mpix_per_s`.  Data parallel: one process per GPU, weak scaling (256 patches per GPU),
 ONE all-reduce(AVG) of the flat 2.67 MB gradient per step.
 
-  python bench.py [--gpus N --steps K --warmup W]        (N > 1 under torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: either started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or started bare -- then this process makes no
+GPU call at all and starts its own N ranks as fresh child processes (never an exec), relays rank 0's JSON line
+and exits with the children's worst return code.  With fewer GPUs than ranks (a rehearsal on a one-GPU box) the
+ranks share the visible GPUs and exchange gradients over gloo; the line then says so in `config.rehearsal`.
+
+Extra keys beside the primary metric (rank 0, after the timed region): the other north-star numbers --
+`subpixel` (depth-to-space GB/s at [256,41,41,27], rotating buffers), `espcn_c2_us` (BASELINE configs[1]),
+`srcnn_c1_us` (configs[0] shape), `dgrad` / `wgrad` fractions of the fp32-MFMA peak.
 """
 import argparse
 import json
@@ -132,20 +142,156 @@ def cpu_library_baseline(rank):
         return {'value': None, 'error': repr(exc)}
 
 
+def kernel_source_sha():
+    """sha256 over the HIP sources of libsrx.so: ties a number measured on an earlier build to the code it was
+    measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'ml_super_resolution_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(csrc, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic():
+    """`roofline.traffic` is NOT measured by this run (PMC counters need rocprofv3 around the process): it is the
+    HBM bytes per launch of the dominant kernel from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md), recorded in profiles/traffic.json together with the kernel name and
+    the sha of the kernel sources it was measured on.  If the sources have changed since, the value is withheld
+    (null) rather than silently carried over."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except (OSError, ValueError):
+        return {'traffic': None, 'traffic_source': None}
+    sha = kernel_source_sha()
+    if rec.get('csrc_sha') != sha:
+        return {'traffic': None, 'traffic_source': rec.get('source'), 'traffic_stale': 'measured on csrc %s, this build is %s'
+                % (rec.get('csrc_sha'), sha)}
+    return {'traffic': rec['traffic_bytes'], 'traffic_algorithmic': rec.get('algorithmic_bytes'),
+            'traffic_source': rec.get('source'), 'traffic_kernel': rec.get('kernel'), 'traffic_csrc_sha': sha}
+
+
+def extras(model, dev, stream, x64, y64, px):
+    """The other north-star numbers, measured after the timed region with HIP events on the launch stream."""
+    from ml_super_resolution_amd import ops
+    from ml_super_resolution_amd.espcn import model_espcn
+    from ml_super_resolution_amd.srcnn import srcnn as srcnn_mod
+    out = {}
+    # -- dgrad / wgrad of the 3x3 64->64 layer (same algorithmic FLOPs as the forward launch)
+    k = model.stack.kernel(5)
+    dx = torch.empty_like(x64)
+    dw, db = torch.empty_like(k), torch.empty(64, device=dev)
+    ws = torch.empty((ops.bwd_filter_workspace_bytes(x64.shape, k.shape) + 3) // 4, device=dev)
+    f_dgrad = lambda: ops.conv2d_bwd_data(y64, k, x64.shape, 'same', x_in=x64, in_act='relu', out=dx)
+    f_wgrad = lambda: ops.conv2d_bwd_filter(x64, y64, k.shape, 'same', w_for_decay=k, wd_scale=1e-4, dw=dw, dbias=db,
+                                            workspace=ws)
+    for name, fn in (('dgrad', f_dgrad), ('wgrad', f_wgrad)):
+        fn()
+        ms = hip_event_time_ms(fn, 20, stream)
+        tf = MID_LAYER_FLOP_PER_PX * px / (ms * 1e-3) / 1e12
+        out[name] = {'launch_ms': round(ms, 4), 'achieved': round(tf, 2), 'unit': 'TFLOP/s',
+                     'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                     'what': '3x3 64->64 %s at 256x41x41%s' % (name, ' incl. the reduction of the partial filters and the '
+                                                             'regulariser term' if name == 'wgrad' else ' + fused ReluGrad')}
+    del dx, ws
+    # -- sub-pixel map at the north-star bandwidth shape, 8 rotating buffer pairs (744 MB > Infinity Cache)
+    pairs = 8
+    ins = [torch.rand((256, 41, 41, 27), device=dev) for _ in range(pairs)]
+    outs = [torch.empty((256, 123, 123, 3), device=dev) for _ in range(pairs)]
+    state = {'i': 0}
+
+    def d2s():
+        i = state['i'] = (state['i'] + 1) % pairs
+        ops.depth_to_space(ins[i], 3, out=outs[i])
+    for _ in range(pairs):
+        d2s()
+    ms = hip_event_time_ms(d2s, 10 * pairs, stream)
+    nbytes = 2.0 * ins[0].numel() * 4
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    out['subpixel'] = {'bound': 'hbm', 'kernel': 'subpixel_lds_kernel (standalone depth-to-space [256,41,41,27] -> [256,123,123,3])',
+                       'launch_us': round(ms * 1e3, 2), 'bytes': nbytes, 'achieved': round(gbps, 1), 'peak': 8000.0,
+                       'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4), 'rotating_pairs': pairs}
+    del ins, outs
+    # -- BASELINE configs[1]: ESPCN 3x inference, batch 32 of 17x17 LR patches: forward + depth-to-space
+    e3 = model_espcn.EspcnModel(3, device=dev, seed=103)
+    lr = torch.rand((32, 17, 17, 3), device=dev) * 2 - 1
+    sr_fn = lambda: e3.super_resolve(lr)
+    for _ in range(5):
+        sr_fn()
+    us = hip_event_time_ms(sr_fn, 200, stream) * 1e3
+    out['espcn_c2_us'] = round(us, 2)
+    out['espcn_c2_hr_mpix_per_s'] = round(32 * 51 * 51 / us, 1)
+    out['espcn_c2_tflops'] = round(573.5e6 / (us * 1e-6) / 1e12, 2)
+    out['espcn_c2_path'] = getattr(e3, 'inference_path', 'eager: 3 conv launches + depth-to-space')
+    # -- BASELINE configs[0] shape as the reference would run it: SRCNN 9-1-5 VALID on one 243x243 RGB image
+    sm = srcnn_mod.SrcnnModel(device=dev, seed=101)
+    for i in range(3):                                   # O(1) activations instead of the reference's sigma 1e-3
+        sm.stack.kernel(i).mul_(60.0)
+    img = torch.rand((1, 243, 243, 3), device=dev) * 2 - 1
+    c1 = lambda: sm.forward(img)
+    for _ in range(5):
+        c1()
+    us = hip_event_time_ms(c1, 100, stream) * 1e3
+    out['srcnn_c1_us'] = round(us, 2)
+    out['srcnn_c1_tflops'] = round(2200e6 / (us * 1e-6) / 1e12, 2)
+    return out
+
+
+def launch_ranks(n):
+    """Start N ranks of this script as fresh child processes and wait for them.  Runs BEFORE this process has
+    made any GPU call (device_count() does not initialise HIP), and never execs: the children are ordinary
+    subprocesses with the torchrun environment, the parent only relays their output and return codes."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ndev = torch.cuda.device_count()
+    base = dict(os.environ)
+    base['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    if ndev < n:
+        base.setdefault('SRX_DIST_BACKEND', 'gloo')      # several ranks per GPU: RCCL needs one GPU per rank
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    pending = list(procs)
+    failed_at = None
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is not None:
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    failed_at = failed_at or time.time()
+        if failed_at is not None and pending and time.time() - failed_at > 20:
+            for p in pending:                           # a rank died: its peers would wait in a collective forever
+                p.kill()                                # (exactly the PIDs started above)
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary north-star numbers')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
     ndev = torch.cuda.device_count()
@@ -160,8 +306,10 @@ def main():
         srx_dist.init_process_group(rank, world, local_rank)
 
     model = model_vdsr.VdsrModel(num_layers=20, use_adam=True, device=dev, seed=106)
+    backend = None
     if world > 1:
-        srx_dist.attach(model.stack, world)
+        srx_dist.attach(model.stack, world, timed=True)
+        backend = torch.distributed.get_backend()
 
     # synthetic patches: rank r uses seeds 104+10r / 105+10r
     g = torch.Generator(device=dev).manual_seed(104 + 10 * rank)
@@ -187,15 +335,16 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    allreduce_ms = srx_dist.allreduce_ms(model.stack, last=args.steps) if world > 1 else None
     if world > 1:
-        nccl = torch.distributed.get_backend() == 'nccl'
+        nccl = backend == 'nccl'
         t = torch.tensor([dt], dtype=torch.float64, device=dev if nccl else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     patches_per_s = world * BATCH * args.steps / dt
 
-    # ---- forward-only rate and the dominant kernel's roofline (rank 0, HIP events on the launch stream)
+    # ---- forward-only rate and the dominant kernels' rooflines (rank 0, HIP events on the launch stream)
     stream = torch.cuda.current_stream()
     px = BATCH * SIZE * SIZE
     fwd_ms = hip_event_time_ms(lambda: model.forward(sd), 10, stream)
@@ -209,26 +358,33 @@ def main():
     train_tf = TRAIN_FLOP_PER_PX * px / (ms_per_step * 1e-3) / 1e12
 
     if rank == 0:
+        cfg = {'workload': 'BASELINE configs[2]: VDSR 20-layer 3x3x64 residual, RGB, batch 256x41x41 '
+                           'per GPU, fwd+bwd+TF-Adam, random-init weights',
+               'global_batch': world * BATCH, 'patch': SIZE, 'parallelism': 'dp%d' % world}
+        if world > 1:
+            cfg['collective'] = 'one all_reduce(AVG) of %d floats per step, backend %s' % (model.stack.flat_size, backend)
+            if ndev < world:
+                cfg['rehearsal'] = '%d ranks share %d GPU(s); gradients exchanged over %s through the host -- a ' \
+                                   'functional rehearsal of the N>1 path, not a scaling measurement' % (world, ndev, backend)
         line = {
             'metric': 'VDSR-20 training patches/sec (41x41, batch 256 per GPU); fwd HR megapixels/sec alongside',
             'value': round(patches_per_s, 1), 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: VDSR 20-layer 3x3x64 residual, RGB, batch 256x41x41 '
-                                   'per GPU, fwd+bwd+TF-Adam, random-init weights',
-                       'global_batch': world * BATCH, 'patch': SIZE, 'parallelism': 'dp%d' % world},
+            'config': cfg,
             'fwd_hr_mpix_per_s': round(px / (fwd_ms * 1e-3) / 1e6, 2),
             'fwd_ms': round(fwd_ms, 3),
             'train_step_tflops': round(train_tf, 2),
             'train_step_frac_of_fp32_mfma_peak': round(train_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_pipe_kernel<3,3,64,4,fwd> (3x3 64->64 fwd+bias+ReLU)',
-                         'achieved': round(achieved_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (2*FETCH_SIZE +
-                         # WRITE_SIZE, gfx950 correction); algorithmic bytes are 220.3e6 (input + output once)
-                         'traffic': 2.225e8, 'traffic_source': 'profiles/r01_prof_conv_hbm_counters.csv',
-                         'launch_ms': round(mid_ms, 4)},
+            'roofline': dict({'bound': 'mfma', 'kernel': 'conv_pipe_kernel<3,3,64,4,fwd> (3x3 64->64 fwd+bias+ReLU)',
+                              'achieved': round(achieved_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'launch_ms': round(mid_ms, 4)}, **measured_traffic()),
         }
+        if allreduce_ms is not None:
+            line['allreduce_ms'] = round(allreduce_ms, 4)
+        if not args.no_extras:
+            line.update(extras(model, dev, stream, x64, y64, px))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rank)
             line['cpu_library_baseline'] = cpu_library_baseline(rank)

@@ -45,7 +45,7 @@ struct ConvArgs {
     int act, post_relu, mask_act;
     float inv_rs;         // 1/RS
     int stagger;          // s_sleep(127) count for the second resident workgroup (0 = off)
-    int dbg;              // diagnostic timing knobs (SRX_DBG): 1 = stage only the first tile, 2 = no stores
+    int dbg;              // diagnostic timing knobs, compiled in only with -DSRX_TRACE (SRX_DBG: 1 = stage only the first tile, 2 = no stores)
     unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
     int buf_floats;       // pipelined kernel: floats per LDS tile buffer (two buffers)
     int* tile_counter;    // dynamic scheduling (two-workgroup kernels): next tile to hand out, preset to gridDim.x; null = static
@@ -264,7 +264,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4
                 if (a.post_relu) v = act_apply4(v, ACT_RELU, 0.0f);
                 if (a.mask) v = act_grad4(v, aux[i], a.mask_act, mslope);
             }
-            if ((a.dbg & 2) && v[0] != 12345.678f) continue;
+#ifdef SRX_TRACE
+            if ((a.dbg & 2) && v[0] != 12345.678f) continue;      // diagnostic builds: no stores
+#endif
             if (valid[i]) *reinterpret_cast<f32x4*>(yb + off[i]) = v;
         }
     } else {
@@ -606,13 +608,15 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
         const int n_need = (th + KH - 1) * a.RS + (KW - 1);
-        const bool first_tile = dyn ? (tile == (int)blockIdx.x) : (u == u0);
+        [[maybe_unused]] const bool first_tile = dyn ? (tile == (int)blockIdx.x) : (u == u0);
 
         const unsigned long long ts_stage = SRX_STAMP();
         lds_barrier();
         const unsigned long long ts_b1 = SRX_STAMP();
         if (dyn && tid == 0) *mailbox = atomicAdd(a.tile_counter, 1);     // the NEXT tile, fetched early
-        if (!(a.dbg & 1) || first_tile)
+#ifdef SRX_TRACE
+        if (!(a.dbg & 1) || first_tile)                       // diagnostic builds: stage only the first tile
+#endif
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
         const unsigned long long ts_ld = SRX_STAMP();
         lds_barrier();

@@ -2,6 +2,7 @@
 // kernel-instance dispatch.  No device synchronisation, no allocation.
 #include <math.h>
 #include <stdarg.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,7 +16,58 @@ using namespace srx;
 namespace {
 
 thread_local char g_err[512] = "";
-int g_use_pipe = -1;   // conv kernel family, see srx_set_conv_path
+
+// Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
+// the ABI promises concurrent calls from several host threads on different streams.
+struct Knobs {
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, fused_reduce;
+    unsigned long long* trace;
+    int dbg;
+};
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+Knobs read_knobs() {
+    Knobs k;
+    k.pipe_default = env_int("SRX_PIPE", 1);
+    k.min_full_th = env_int("SRX_MIN_FULL_TH", 3);   // full-width tiles of 1-2 rows re-stage 3 input rows per output row: measured slower than column tiles
+    k.small_rule = env_int("SRX_SMALL_RULE", 1);     // 0: tallest tile that leaves two per slot (A/B)
+    k.th = env_int("SRX_TH", -1);                    // force the tile height (tuning experiments; clamped to what fits)
+    k.grid = env_int("SRX_GRID", -1);
+    k.narrow = env_int("SRX_NARROW", 1);
+    k.dyn = env_int("SRX_DYN", 0);
+    k.stagger = env_int("SRX_STAGGER", -1);
+    k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
+    k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
+    k.fused_reduce = env_int("SRX_FUSED_REDUCE", 1);
+    k.trace = nullptr;
+    k.dbg = 0;
+#ifdef SRX_TRACE
+    { const char* tp = getenv("SRX_TRACE_PTR"); k.trace = tp ? (unsigned long long*)strtoull(tp, nullptr, 0) : nullptr; }
+    k.dbg = env_int("SRX_DBG", 0);                   // diagnostic builds only (make EXTRA=-DSRX_TRACE)
+#endif
+    return k;
+}
+const Knobs& knobs() { static const Knobs k = read_knobs(); return k; }
+
+// conv kernel family, see srx_set_conv_path: -1 = not set by the caller (the environment's default applies)
+std::atomic<int> g_use_pipe{-1};
+int use_pipe() { const int v = g_use_pipe.load(std::memory_order_relaxed); return v < 0 ? knobs().pipe_default : v; }
+
+// Compute units of the current device (persistent-workgroup grids are sized from it): queried once per device.
+// Without a device (host-only workspace queries on a build box) the MI355X's 256.
+int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;
+    }
+    if (n > 256) n = 256;     // grids and partial counts are planned for at most 2 x 256 persistent workgroups
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -28,8 +80,9 @@ int fail(int code, const char* fmt, ...) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr size_t kLdsBudget = 80 * 1024 - 336;  // two workgroups per CU (160 KiB); 320 B spare for wgrad's zero slot
-constexpr int kMaxGrid = 512;             // 2 persistent workgroups x 256 CUs
-constexpr int kPipeGrid = 256;            // pipelined kernels: 1 persistent workgroup per CU
+constexpr int kMaxGridLimit = 512;        // upper bound of any persistent grid (2 x 256 CUs): sizes the partial-count check
+inline int max_grid() { return 2 * cu_count(); }   // two persistent workgroups per CU
+inline int pipe_grid() { return cu_count(); }      // pipelined kernels: one persistent workgroup per CU
 
 struct Plan {
     int KH, KW, cinp, nch;
@@ -62,9 +115,8 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     if (RS < OW + KW - 1 - (KW - 1 - pad_l)) RS = OW + pad_l;
     int TW = OW, NTX = 1;
     long th_max = ((long)max_slots - (KW - 1)) / RS - (KH - 1);
-    static int min_full_th = -1;
-    if (min_full_th < 0) { const char* e = getenv("SRX_MIN_FULL_TH"); min_full_th = e ? atoi(e) : 3; }   // full-width tiles of 1-2 rows re-stage 3 input rows per output row: measured slower than column tiles
-    if (th_max < min_full_th) {
+    const int kMaxGrid = max_grid();
+    if (th_max < knobs().min_full_th) {
         // column tiling: each tile carries its own halo columns; narrow the tile until it fits
         for (TW = 32; TW >= 8; TW >>= 1) {
             RS = TW + KW - 1;
@@ -84,9 +136,7 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     // tiles (the previous rule) 35-39 us per launch.
     const long rows_total = (long)N * NTX * OH;
     bool small = false, rows_split = false;
-    static int small_rule = -1;
-    if (small_rule < 0) { const char* e = getenv("SRX_SMALL_RULE"); small_rule = e ? atoi(e) : 1; }   // 0: tallest tile that leaves two per slot (A/B)
-    if (!small_rule) {
+    if (!knobs().small_rule) {
         while (th_max > 1 && rows_total / th_max < 2 * kMaxGrid && rows_total >= 64) th_max -= 1;
     } else if (rows_total / th_max < 2 * kMaxGrid && KH == 3 && KW == 3 && p->cinp >= 16 && in_c == p->cinp && lean_epilogue &&
                (out_c & 3) == 0 && RS >= 256 / (p->cinp / 4) && (NTX > 1 ? p->nch == 4 : 16 * (4 / p->nch) <= OW)) {
@@ -118,11 +168,7 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
         const double eff = (double)px / (16.0 * ((px + 15) / 16));
         if (eff > best_eff + 1e-9) { best_eff = eff; best = th; }
     }
-    {
-        static int th_env = -2;     // SRX_TH: force the tile height (tuning experiments; clamped to what fits)
-        if (th_env == -2) { const char* e = getenv("SRX_TH"); th_env = e ? atoi(e) : -1; }
-        if (th_env > 0) best = th_env < th_fit ? th_env : (int)th_fit;
-    }
+    if (knobs().th > 0) best = knobs().th < th_fit ? knobs().th : (int)th_fit;
     p->TH = best; p->TW = TW; p->NTX = NTX; p->RS = RS;
     p->units_total = (int)rows_total;
     long g = rows_total / p->TH;
@@ -132,11 +178,7 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     if (rows_split) g = rows_total;
     if (g < 1) g = 1;
     p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
-    {
-        static int genv = -2;
-        if (genv == -2) { const char* e = getenv("SRX_GRID"); genv = e ? atoi(e) : -1; }
-        if (genv > 0 && genv < p->grid) p->grid = genv;
-    }
+    if (knobs().grid > 0 && knobs().grid < p->grid) p->grid = knobs().grid;
     p->lds_bytes = ((size_t)(p->TH + KH - 1) * RS + (KW - 1)) * slot_bytes;
     return SRX_OK;
 }
@@ -179,14 +221,13 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // Main path for the 3x3 body layers: the pipelined one-wave-per-SIMD kernel, one workgroup per CU with
     // two LDS tile buffers (measured 7 % faster than the two-workgroups-per-CU kernels at 256x41x41x64).
     // SRX_PIPE=0 / srx_set_conv_path(0) selects the two-workgroup kernels for everything (A/B).
-    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
+    const int g_use_pipe = use_pipe();
+    const int kMaxGrid = max_grid(), kPipeGrid = pipe_grid();
     // Three output channels (the RGB output layer): 16 lanes per pixel, no MFMA -- see conv_narrow.hip.  (The
     // mirror case, 3 -> 64 channels, was tried the same way and lost to the MFMA kernel: 56 vs 48 us.)
     // SRX_NARROW=0 keeps them on the MFMA kernels (A/B).
     {
-        static int use_narrow = -1;
-        if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
-        if (use_narrow && launch_conv_narrow(k, a, s, &err)) {
+        if (knobs().narrow && launch_conv_narrow(k, a, s, &err)) {
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
@@ -231,8 +272,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // and the "tail" of the static split is not wasted: the workgroup left alone runs unstarved).
     // SRX_DYN=1 enables it when the caller lends a counter word.
     {
-        static int use_dyn = -1;
-        if (use_dyn < 0) { const char* e = getenv("SRX_DYN"); use_dyn = e ? atoi(e) : 0; }
+        const int use_dyn = knobs().dyn;
         const int tiles_per_col = (p.OH + p.TH - 1) / p.TH;
         const long tiles_total = (long)a.N * p.NTX * tiles_per_col;
         a.tile_counter = nullptr;
@@ -262,13 +302,9 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
 // s_sleep(127) iterations (~3.4 us each) by which the second workgroup of a CU is delayed; only
 // worth it when every CU really hosts two long-running workgroups.  SRX_STAGGER overrides.
 int stagger_sleeps(const Plan& p) {
-    static int env = -2;
-    if (env == -2) {
-        const char* e = getenv("SRX_STAGGER");
-        env = e ? atoi(e) : -1;
-    }
+    const int env = knobs().stagger;
     if (env >= 0) return env;
-    if (p.grid < kMaxGrid) return 0;
+    if (p.grid < max_grid()) return 0;
     const long tiles_per_wg = (long)p.units_total / ((long)p.grid * p.TH);
     return tiles_per_wg >= 2 ? 4 : 0;
 }
@@ -280,11 +316,8 @@ void fill_conv_args(ConvArgs* a, const Plan& p, int N, int H, int W, int in_c, i
     a->units_total = p.units_total;
     a->inv_rs = 1.0f / (float)p.RS;
     a->stagger = stagger_sleeps(p);
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("SRX_DBG"); dbg = e ? atoi(e) : 0; }
-    a->dbg = dbg;
-    const char* tp = getenv("SRX_TRACE_PTR");   // diagnostic builds only
-    a->trace = tp ? (unsigned long long*)strtoull(tp, nullptr, 0) : nullptr;
+    a->dbg = knobs().dbg;        // both zero / null unless built with -DSRX_TRACE
+    a->trace = knobs().trace;
 }
 
 }  // namespace
@@ -294,10 +327,8 @@ extern "C" {
 const char* srx_version(void) { return "srx 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 const char* srx_last_error(void) { return g_err; }
 int srx_set_conv_path(int pipelined) {
-    if (g_use_pipe < 0) { const char* e = getenv("SRX_PIPE"); g_use_pipe = e ? atoi(e) : 1; }
-    const int old = g_use_pipe;
-    g_use_pipe = pipelined ? 1 : 0;
-    return old;
+    const int old = g_use_pipe.exchange(pipelined ? 1 : 0, std::memory_order_relaxed);
+    return old < 0 ? knobs().pipe_default : old;
 }
 size_t srx_reduce_scratch_bytes(void) { return (size_t)kReduceBlocks * sizeof(float); }
 
@@ -379,22 +410,21 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
     a.stagger = stagger_sleeps(p);
     a.zero_slot = (p.TH + d->KH - 1) * p.RS + (d->KW - 1);      // first slot after the largest tile
-    { const char* tp = getenv("SRX_TRACE_PTR"); a.trace = tp ? (unsigned long long*)strtoull(tp, nullptr, 0) : nullptr; }   // diagnostic builds only
+    a.trace = knobs().trace;   // diagnostic builds only
     const size_t wg_lds = p.lds_bytes + (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
     // Linear-walk kernel for full-width tiles (see wgrad_lin_kernel); SRX_WGRAD_LIN=0 selects the cursor kernel (A/B).
-    static int use_lin = -1;
-    if (use_lin < 0) { const char* e = getenv("SRX_WGRAD_LIN"); use_lin = e ? atoi(e) : 1; }
+    const int use_lin = knobs().wgrad_lin;
+    const int kPipeGrid = pipe_grid();
     const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && p.RS == d->W + pl && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
     // (its last step may read up to 3 slots past the tile: they are allocated and zeroed, their dpre operand is 0)
     const size_t lin_lds = p.lds_bytes + 4 * (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     // one workgroup per CU, two tile buffers (wgrad_pipe_kernel): exact-fit channels, a row stride of at least one pass;
     // SRX_WGRAD_PIPE=0 keeps the two-workgroup kernel (A/B)
-    static int use_wpipe = -1;
-    if (use_wpipe < 0) { const char* e = getenv("SRX_WGRAD_PIPE"); use_wpipe = e ? atoi(e) : 1; }
+    const int use_wpipe = knobs().wgrad_pipe;
     const int wppp = (p.cinp >= 16) ? 256 / (p.cinp / 4) : 256;
     int wgrid = p.grid;
     bool wdone = false;
@@ -421,9 +451,7 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     }
     {
         // 64 <-> 3 channel layers: 16 lanes per position, no MFMA (conv_narrow.hip); SRX_NARROW=0 for A/B
-        static int use_narrow = -1;
-        if (use_narrow < 0) { const char* e = getenv("SRX_NARROW"); use_narrow = e ? atoi(e) : 1; }
-        if (!wdone && use_narrow) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
+        if (!wdone && knobs().narrow) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
     }
     // column strips: exact-fit channels and a tile row of at least one staging pass (the strip stager is the scalar one)
     // (and every strip, the narrower last one included, at least one 4-position step wide: the lanes of a step that
@@ -447,7 +475,7 @@ int srx_conv2d_bwd_filter_reduce(const srx_conv_desc* d, const void* ws, int n_p
     int rc = check_desc(d);
     if (rc) return rc;
     if (!ws || !dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
-    if (n_partials <= 0 || n_partials > kMaxGrid) return fail(SRX_ERR_BAD_ARG, "bad partial count %d", n_partials);
+    if (n_partials <= 0 || n_partials > kMaxGridLimit) return fail(SRX_ERR_BAD_ARG, "bad partial count %d", n_partials);
     const size_t wn = (size_t)d->KH * d->KW * d->Cin * d->Cout;
     hipError_t err = launch_reduce_partials((const float*)ws, n_partials, (int)part_stride(d), (int)wn, d->Cout, dw, dbias,
                                             w_for_decay, wd_scale, (hipStream_t)stream);

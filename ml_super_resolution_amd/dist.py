@@ -43,16 +43,64 @@ def allreduce_mean_(flat, world_size):
     return flat
 
 
-def attach(stack, world_size):
-    """Install the gradient all-reduce on a ConvStack and make the replicas start identical."""
-    if td.get_backend() != 'nccl' and stack.params.is_cuda:
-        host = stack.params.detach().cpu()
-        td.broadcast(host, src=0)
-        stack.params.copy_(host)
+def broadcast_(t, src=0):
+    """In-place broadcast of a tensor from rank `src` (through the host for device tensors on gloo)."""
+    if td.get_backend() != 'nccl' and t.is_cuda:
+        host = t.detach().cpu()
+        td.broadcast(host, src=src)
+        t.copy_(host)
     else:
-        td.broadcast(stack.params, src=0)
-    stack.grad_hook = lambda g: allreduce_mean_(g, world_size)
+        td.broadcast(t, src=src)
+    return t
+
+
+def attach(stack, world_size, timed=False):
+    """Install the gradient all-reduce on a ConvStack and make the replicas start identical: parameters,
+    `global_step` and the optimizer slots all come from rank 0 (a rank that resumed from a different
+    checkpoint -- or none -- would otherwise run a different number of steps and hang the collective).
+    timed=True: every hook call is bracketed by two events on the launch stream, kept in
+    `stack.allreduce_events`, so the caller can report where a scaling loss goes (bench.py `allreduce_ms`)."""
+    broadcast_(stack.params, 0)
+    if hasattr(stack, 'global_step'):
+        # [global_step, has opt_m, has opt_v] of rank 0
+        head = torch.tensor([stack.global_step, int(stack.opt_m is not None), int(stack.opt_v is not None)],
+                            dtype=torch.int64)
+        if td.get_backend() == 'nccl':
+            head = head.to(stack.params.device)
+        td.broadcast(head, src=0)
+        step, has_m, has_v = (int(v) for v in head.tolist())
+        stack.global_step = step
+        for flag, name in ((has_m, 'opt_m'), (has_v, 'opt_v')):
+            if flag:
+                if getattr(stack, name) is None:
+                    setattr(stack, name, torch.zeros_like(stack.params))
+                broadcast_(getattr(stack, name), 0)
+            else:
+                setattr(stack, name, None)
+    stack.allreduce_events = []
+
+    def hook(g):
+        if timed and g.is_cuda:
+            s = torch.cuda.current_stream(g.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            allreduce_mean_(g, world_size)
+            e1.record(s)
+            stack.allreduce_events.append((e0, e1))
+        else:
+            allreduce_mean_(g, world_size)
+        return g
+
+    stack.grad_hook = hook
     return stack
+
+
+def allreduce_ms(stack, last=None):
+    """Mean duration (ms) of the timed hook calls recorded by attach(timed=True); call after a synchronize."""
+    ev = stack.allreduce_events[-last:] if last else stack.allreduce_events
+    if not ev:
+        return None
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
 
 def shard(batch, rank, world_size):

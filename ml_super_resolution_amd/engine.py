@@ -150,7 +150,9 @@ class ConvStack(object):
             if keep:
                 out = self._buf(('act', i), shapes[i])
             else:
-                out = self._buf(('tmp', i & 1, shapes[i]), shapes[i])
+                # keyed by parity and channel count, not by the full shape: a new image size replaces the old
+                # buffer instead of piling up one pair per size (a directory of images of many sizes)
+                out = self._buf(('tmp', i & 1, s.cout), shapes[i])
             t = ops.conv2d_fwd(t, self.kernel(i), self.bias(i), s.padding, s.act, skip=skip, out=out)
             acts.append(t)
         self._acts = acts if keep else None
@@ -181,10 +183,13 @@ class ConvStack(object):
             dpre = ops.act_bwd(dy, y, self.specs[last].act, out=self._buf(('dpre_last',), y.shape))
         else:
             dpre = dy
-        if self._ws is None:
-            need = max(ops.bwd_filter_workspace_bytes(acts[i].shape, s.kernel_shape, s.padding)
-                       for i, s in enumerate(self.specs))
+        # the number of partial filters grows with batch and image size: re-query on every call (host-only) and
+        # grow the workspace when a larger feed arrives
+        need = max(ops.bwd_filter_workspace_bytes(acts[i].shape, s.kernel_shape, s.padding)
+                   for i, s in enumerate(self.specs))
+        if self._ws is None or self._ws.numel() * 4 < need:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            self._ws2 = None
         # dgrad of layer i and wgrad (+ partial reduce) of layer i are independent: both only read dpre_i.  With
         # SRX_OVERLAP_WGRAD=1 the wgrads run on a side stream, so that their prologues, the reduce kernels and the ragged
         # ends of the launches could overlap the dgrad chain.  Measured on MI355X: 14.59 ms per step against 14.45 ms
@@ -203,7 +208,7 @@ class ConvStack(object):
         if red:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-            if self._ws2 is None:
+            if self._ws2 is None or self._ws2.numel() != self._ws.numel():
                 self._ws2 = torch.empty_like(self._ws)
         ws_free = [None, None]   # event: the reduction reading workspace k has finished
         read_done = {}       # id of a rotating buffer -> event: the wgrad reading it has finished
@@ -244,7 +249,7 @@ class ConvStack(object):
                                       dbias=self.bias(i, self.grads), workspace=self._ws)
             if i > 0:
                 prev_act = self.specs[i - 1].act
-                out = self._buf(('dx', i % 3, acts[i].shape), acts[i].shape)
+                out = self._buf(('dx', i % 3, acts[i].shape[3]), acts[i].shape)
                 if two and out.data_ptr() in read_done:
                     main.wait_event(read_done.pop(out.data_ptr()))
                 dpre = ops.conv2d_bwd_data(dpre, self.kernel(i), acts[i].shape, s.padding,
@@ -289,13 +294,20 @@ class ConvStack(object):
         return sd
 
     # ---- TensorFlow V2 checkpoints (tf.train.Saver format; tf_bundle.py) --------------------------
-    def tf_checkpoint_tensors(self, adam_betas=(0.9, 0.999)):
+    def tf_checkpoint_tensors(self, adam_betas=(0.9, 0.999), extra=None):
         """{checkpoint key: ndarray} as tf.train.Saver would write this model: `<scope>/kernel`, `<scope>/bias`,
         `global_step` (int64) and, when an optimizer has run, its slots: Adam `<var>/Adam`, `<var>/Adam_1`,
-        `beta1_power`, `beta2_power`; Momentum `<var>/Momentum`."""
+        `beta1_power`, `beta2_power`; Momentum `<var>/Momentum`.  `extra`: further global variables of the
+        reference graph ({name: array}; VDSR's non-trainable `learning_rate`, vdsr/vdsr/model_vdsr.py:136-141 --
+        Saver().restore needs every global variable to be present).
+        beta powers: TF-1.x AdamOptimizer creates them with the value beta and multiplies them by beta once per
+        apply (_finish), so after N steps the checkpoint holds beta ** (N + 1).  (From the TF 1.8 optimizer as
+        remembered: the source is not available here, and no TF-written checkpoint exists to check against.)"""
         import numpy as np
         out = {k: v.detach().cpu().numpy() for k, v in self.variables().items()}
         out['global_step'] = np.asarray(self.global_step, dtype=np.int64)
+        for k, v in (extra or {}).items():
+            out[k] = np.asarray(v)
         if self.opt_m is not None:
             two = self.opt_v is not None
             for i, s in enumerate(self.specs):
@@ -305,13 +317,18 @@ class ConvStack(object):
                     if two:
                         out['%s/%s/Adam_1' % (scope, kind)] = view(i, self.opt_v).detach().cpu().numpy()
             if two:
-                out['beta1_power'] = np.asarray(adam_betas[0] ** self.global_step, dtype=np.float32)
-                out['beta2_power'] = np.asarray(adam_betas[1] ** self.global_step, dtype=np.float32)
+                out['beta1_power'] = np.asarray(adam_betas[0] ** (self.global_step + 1), dtype=np.float32)
+                out['beta2_power'] = np.asarray(adam_betas[1] ** (self.global_step + 1), dtype=np.float32)
         return out
 
-    def save_tf_checkpoint(self, prefix, adam_betas=(0.9, 0.999)):
+    def save_tf_checkpoint(self, prefix, adam_betas=(0.9, 0.999), extra=None, write_state=True):
+        """Writes `<prefix>.index` + `<prefix>.data-00000-of-00001` and (write_state) the `checkpoint` state file
+        (CheckpointState text proto) next to them, which is what tf.train.latest_checkpoint(dir) reads
+        (vdsr/vdsr/experiment_train.py:108)."""
         from . import tf_bundle
-        tf_bundle.save_checkpoint(prefix, self.tf_checkpoint_tensors(adam_betas))
+        tf_bundle.save_checkpoint(prefix, self.tf_checkpoint_tensors(adam_betas, extra))
+        if write_state:
+            tf_bundle.update_checkpoint_state(prefix)
 
     def load_tf_checkpoint(self, prefix, with_optimizer=True):
         """Restores kernels / biases (and global_step, optimizer slots when present) from a checkpoint written by

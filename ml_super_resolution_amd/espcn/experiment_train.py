@@ -1,7 +1,9 @@
 """
 experiment_train.py -- mirror of espcn/espcn/experiment_train.py: flags, LR schedule
-lr0 * factor ** (step // decay_steps) (:101-107), loop until stop_training_at_k_step, one
-checkpoint at the end (:130).  The reference reads pre-shuffled TFRecords; here batches come from a
+lr0 * factor ** (step // decay_steps) (:101-107), resume from the latest checkpoint under ckpt_path when
+one exists (:78-88), loop until stop_training_at_k_step, one checkpoint at the end (:130) -- a TensorFlow
+V2 bundle `model.ckpt-<step>` with the reference's variable names (f1..f3 kernel / bias, Adam slots,
+beta powers, global_step) plus the `checkpoint` state file.  The reference reads pre-shuffled TFRecords; here batches come from a
 synthetic generator or an .npz of (lr_patches, hr_patches): HR patches are mapped to the sub-pixel
 label layout ON THE GPU with space_to_depth (dataset.py:140-156).
 """
@@ -34,7 +36,7 @@ def npz_batches(path, batch_size, device, seed=0):
         yield torch.from_numpy(lr_all[idx]).to(device), torch.from_numpy(hr_all[idx]).to(device)
 
 
-def main():
+def parse_flags(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--data_path', default=None)
     ap.add_argument('--ckpt_path', default=None)
@@ -46,10 +48,32 @@ def main():
     ap.add_argument('--learning_rate_decay_factor', type=float, default=0.1)
     ap.add_argument('--learning_rate_decay_steps', type=int, default=2560)
     ap.add_argument('--stop_training_at_k_step', type=int, default=10000)
-    FLAGS = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def latest_checkpoint(ckpt_path):
+    """tf.train.latest_checkpoint(ckpt_path): the state file first, then the highest-numbered bundle."""
+    from .. import tf_bundle
+    if not ckpt_path or not os.path.isdir(ckpt_path):
+        return None
+    found = tf_bundle.latest_checkpoint(ckpt_path)
+    if found is not None:
+        return found
+    steps = {}
+    for name in os.listdir(ckpt_path):
+        if name.startswith('model.ckpt-') and name.endswith('.index'):
+            steps[int(name[len('model.ckpt-'):-len('.index')])] = os.path.join(ckpt_path, name[:-len('.index')])
+    return steps[max(steps)] if steps else None
+
+
+def main(argv=None, log=None):
+    """`log`: optional callable receiving one dict per step (tests)."""
+    FLAGS = parse_flags(argv)
     device = torch.device('cuda')
     m = model_espcn.EspcnModel(FLAGS.scaling_factor, device=device)
+    source = latest_checkpoint(FLAGS.ckpt_path)
+    if source is not None:
+        m.stack.load_tf_checkpoint(source)               # weights, Adam slots, global_step (:78-88)
     batches = (npz_batches(FLAGS.data_path, FLAGS.batch_size, device) if FLAGS.data_path
                else synthetic_batches(FLAGS.batch_size, FLAGS.lr_patch_size, FLAGS.scaling_factor, device))
     step = m.stack.global_step
@@ -59,11 +83,15 @@ def main():
         hr_target = ops.space_to_depth(hr_patch, FLAGS.scaling_factor)
         loss = m.train_step(lr_patch, hr_target, lr_rate)
         step = m.stack.global_step
+        if log is not None:
+            log({'step': step, 'lr': lr_rate, 'loss': loss.item()})
         if step % 100 == 0:
-            print('step %d loss %.6f lr %g' % (step, loss.item(), lr_rate))
+            print('step %d loss %.6f lr %g' % (step, loss.item(), lr_rate), flush=True)
     if FLAGS.ckpt_path:
         os.makedirs(FLAGS.ckpt_path, exist_ok=True)
-        m.save(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d.npz' % step))
+        # saver.save(session, ckpt_path/model.ckpt, global_step=step) (:130)
+        m.stack.save_tf_checkpoint(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d' % step))
+    return m
 
 
 if __name__ == '__main__':

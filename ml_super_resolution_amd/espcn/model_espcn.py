@@ -63,23 +63,26 @@ class EspcnModel(object):
     def run(self, keys, feed_dict):
         dev = self.stack.device
         feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}
-        if 'lr_source' not in feeds:
-            raise ValueError('lr_source must be fed')
-        lr = graph.to_device(feeds['lr_source'], dev)
-        hr = graph.to_device(feeds['hr_target'], dev) if 'hr_target' in feeds else None
-        loss = None
-        if 'optimizer' in keys:
-            if hr is None or 'learning_rate' not in feeds:
-                raise ValueError('hr_target and learning_rate must be fed to run the optimizer')
-            loss = self.train_step(lr, hr, float(feeds['learning_rate']))
-            y = self.stack.acts[-1]
-        else:
-            y = self.stack.forward(lr, keep=True)
-            if 'loss' in keys:
-                if hr is None:
-                    raise ValueError('hr_target must be fed to fetch loss')
-                loss = self.stack.loss
-                ops.mse_fwd_bwd(y, hr, loss, accumulate=False, want_grad=False)
+        # `step` is a variable: the reference reads it with no feed (espcn/espcn/experiment_train.py:92)
+        needs_forward = [k for k in keys if k != 'step']
+        lr = hr = y = loss = None
+        if needs_forward:
+            if 'lr_source' not in feeds:
+                raise ValueError('lr_source must be fed to fetch %s' % ', '.join(needs_forward))
+            lr = graph.to_device(feeds['lr_source'], dev)
+            hr = graph.to_device(feeds['hr_target'], dev) if 'hr_target' in feeds else None
+            if 'optimizer' in keys:
+                if hr is None or 'learning_rate' not in feeds:
+                    raise ValueError('hr_target and learning_rate must be fed to run the optimizer')
+                loss = self.train_step(lr, hr, float(feeds['learning_rate']))
+                y = self.stack.acts[-1]
+            else:
+                y = self.stack.forward(lr, keep=True)
+                if 'loss' in keys:
+                    if hr is None:
+                        raise ValueError('hr_target must be fed to fetch loss')
+                    loss = self.stack.loss
+                    ops.mse_fwd_bwd(y, hr, loss, accumulate=False, want_grad=False)
         out = {}
         for k in keys:
             if k == 'optimizer':

@@ -21,6 +21,10 @@ def _chk(t, name):
         return
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise ValueError('%s must be a contiguous float32 tensor on the GPU' % name)
+    if t.device.index != torch.cuda.current_device():
+        # the launch goes to the CURRENT device's current stream: a tensor of another GPU would be read from the
+        # wrong device (one process per GPU: call torch.cuda.set_device(local_rank) first)
+        raise ValueError('%s lives on %s but the current device is cuda:%d' % (name, t.device, torch.cuda.current_device()))
 
 
 def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False):

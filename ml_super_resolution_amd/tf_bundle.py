@@ -460,5 +460,41 @@ def save_checkpoint(prefix, tensors):
     write_table(prefix + '.index', [(b'', header)] + items)
 
 
+def update_checkpoint_state(prefix):
+    """Writes `<dir>/checkpoint`, the CheckpointState text proto that tf.train.Saver.save maintains and
+    tf.train.latest_checkpoint(dir) reads (vdsr/vdsr/experiment_train.py:108): the newest prefix as
+    `model_checkpoint_path`, every known prefix under `all_model_checkpoint_paths` (paths relative to the
+    directory, as the Saver writes them)."""
+    d = os.path.dirname(os.path.abspath(prefix))
+    name = os.path.basename(prefix)
+    state = os.path.join(d, 'checkpoint')
+    known = []
+    if os.path.exists(state):
+        for line in open(state):
+            line = line.strip()
+            if line.startswith('all_model_checkpoint_paths:'):
+                known.append(line.split(':', 1)[1].strip().strip('"'))
+    known = [k for k in known if k != name] + [name]
+    with open(state, 'w') as f:
+        f.write('model_checkpoint_path: "%s"\n' % name)
+        for k in known:
+            f.write('all_model_checkpoint_paths: "%s"\n' % k)
+
+
+def latest_checkpoint(ckpt_dir):
+    """tf.train.latest_checkpoint(dir): the `model_checkpoint_path` of the `checkpoint` state file, if that
+    prefix exists; None otherwise."""
+    state = os.path.join(ckpt_dir, 'checkpoint')
+    if not os.path.exists(state):
+        return None
+    for line in open(state):
+        line = line.strip()
+        if line.startswith('model_checkpoint_path:'):
+            name = line.split(':', 1)[1].strip().strip('"')
+            prefix = name if os.path.isabs(name) else os.path.join(ckpt_dir, name)
+            return prefix if is_checkpoint_prefix(prefix) else None
+    return None
+
+
 def is_checkpoint_prefix(path):
     return isinstance(path, str) and os.path.exists(path + '.index')

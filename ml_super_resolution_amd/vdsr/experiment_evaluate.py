@@ -54,6 +54,8 @@ def main(argv=None):
     print('time (s)     : {}'.format(total / max(len(names), 1)))
     print('psnr (sd, sr): {}, {}'.format(np.mean(sd_psnrs), np.mean(sr_psnrs)))
     print('ssim (sd, sr): {}, {}'.format(np.mean(sd_ssims), np.mean(sr_ssims)))
+    return {'names': names, 'sd_psnrs': sd_psnrs, 'sr_psnrs': sr_psnrs, 'sd_ssims': sd_ssims, 'sr_ssims': sr_ssims,
+            'time': total / max(len(names), 1)}
 
 
 if __name__ == '__main__':

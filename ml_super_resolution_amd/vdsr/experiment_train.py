@@ -40,13 +40,20 @@ def parse_flags(argv=None):
     ap.add_argument('--learning_rate_decay_factor', type=float, default=0.1)
     ap.add_argument('--initial_learning_rate', type=float, default=0.1)
     ap.add_argument('--stop_training_at_k_step', type=int, default=12800)
-    ap.add_argument('--use_adam', type=str2bool, default=True)
+    # tf.app.flags booleans accept a bare `--use_adam` (vdsr/makefile:26) as well as `--use_adam=false`
+    ap.add_argument('--use_adam', type=str2bool, nargs='?', const=True, default=True)
     return ap.parse_args(argv)
 
 
 def latest_checkpoint(ckpt_path):
-    if not ckpt_path:
+    """tf.train.latest_checkpoint(ckpt_path) (:108): the `checkpoint` state file if there is one, else the
+    highest-numbered bundle in the directory."""
+    if not ckpt_path or not os.path.isdir(ckpt_path):
         return None
+    from .. import tf_bundle
+    state = tf_bundle.latest_checkpoint(ckpt_path)
+    if state is not None:
+        return state
     # TensorFlow V2 checkpoints (model.ckpt-N.index + .data-*: what the reference's Saver writes and what this
     # script writes too) and, for older runs of this script, torch state dicts (model.ckpt-N.pt)
     found = {}
@@ -57,7 +64,8 @@ def latest_checkpoint(ckpt_path):
     return found[max(found)] if found else None
 
 
-def main(argv=None):
+def main(argv=None, log=None):
+    """`log`: optional callable receiving one dict per step (tests); the reference writes TF summaries."""
     FLAGS = parse_flags(argv)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -89,7 +97,9 @@ def main(argv=None):
         batches = dataset.npz_batches(FLAGS.data_path, per_rank, device, seed=rank)
     else:
         batches = dataset.synthetic_batches(FLAGS.image_size, per_rank, device, seed=104 + 10 * rank)
-    log = open(os.path.join(FLAGS.logs_path, 'train.jsonl'), 'a') if (FLAGS.logs_path and rank == 0) else None
+    if FLAGS.logs_path and rank == 0:
+        os.makedirs(FLAGS.logs_path, exist_ok=True)
+    logfile = open(os.path.join(FLAGS.logs_path, 'train.jsonl'), 'a') if (FLAGS.logs_path and rank == 0) else None
     t0 = time.time()
     while True:
         step = model.stack.global_step
@@ -97,21 +107,28 @@ def main(argv=None):
             if FLAGS.ckpt_path and rank == 0:
                 os.makedirs(FLAGS.ckpt_path, exist_ok=True)
                 # the reference: saver.save(session, ckpt_path/model.ckpt, global_step) (experiment_train.py:100-121)
-                model.stack.save_tf_checkpoint(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d' % step))
+                # plus the graph's other global variable, the non-trainable `learning_rate`
+                # (vdsr/vdsr/model_vdsr.py:136-141): Saver().restore needs it
+                import numpy as np
+                model.stack.save_tf_checkpoint(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d' % step),
+                                               extra={'learning_rate': np.float32(model.learning_rate)})
             break
         lr = FLAGS.initial_learning_rate * (FLAGS.learning_rate_decay_factor ** (step // FLAGS.learning_rate_decay_steps))
         sd_images, hd_images = next(batches)
         loss = model.train_step(sd_images, hd_images, lr)
+        if log is not None:
+            log({'step': step + 1, 'lr': lr, 'loss': loss.item()})
         if (step + 1) % 100 == 0 and rank == 0:
             # the reference's "epoch" summary: loss + mean PSNR(max_val 2.0) of sr vs hd (:80-84)
             psnr = ops.psnr(model.stack.acts[-1], hd_images, 2.0).mean().item()
             rec = {'step': step + 1, 'loss': loss.item(), 'psnr': psnr, 'lr': lr, 'elapsed_s': time.time() - t0}
             print(json.dumps(rec), flush=True)
-            if log:
-                log.write(json.dumps(rec) + '\n')
-                log.flush()
+            if logfile:
+                logfile.write(json.dumps(rec) + '\n')
+                logfile.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
+    return model
 
 
 if __name__ == '__main__':

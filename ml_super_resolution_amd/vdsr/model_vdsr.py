@@ -74,25 +74,30 @@ class VdsrModel(object):
         for name, ph in self.placeholders.items():
             if ph in feed_dict:
                 feeds[name] = feed_dict[ph]
-        if 'sd_images' not in feeds:
-            raise ValueError('sd_images must be fed')
         lr = feeds.get('learning_rate', self.learning_rate)
-        sd = graph.to_device(feeds['sd_images'], dev)
-        hd = graph.to_device(feeds['hd_images'], dev) if 'hd_images' in feeds else None
-        want_train = 'trainer' in keys
-        want_loss = 'loss' in keys
-        if (want_train or want_loss) and hd is None:
-            raise ValueError('hd_images must be fed to fetch loss / trainer')
-        if want_train:
-            loss = self.train_step(sd, hd, float(lr))
-            sr = self.stack.acts[-1]
-        else:
-            sr = self.stack.forward(sd, keep=True)
-            loss = None
-            if want_loss:
-                loss = self.stack.loss
-                ops.mse_fwd_bwd(sr, hd, loss, accumulate=False, want_grad=False)
-                self.stack.add_regulariser_loss()
+        # `step` and `learning_rate` are variables: the reference reads them with no feed at all
+        # (step = session.run(model['step']), vdsr/vdsr/experiment_train.py:126).  Only fetches that need a
+        # forward pass need the image feeds.
+        needs_forward = [k for k in keys if k not in ('step', 'learning_rate')]
+        sd = hd = sr = loss = None
+        if needs_forward:
+            if 'sd_images' not in feeds:
+                raise ValueError('sd_images must be fed to fetch %s' % ', '.join(needs_forward))
+            sd = graph.to_device(feeds['sd_images'], dev)
+            hd = graph.to_device(feeds['hd_images'], dev) if 'hd_images' in feeds else None
+            want_train = 'trainer' in keys
+            want_loss = 'loss' in keys
+            if (want_train or want_loss or 'hd_images' in keys) and hd is None:
+                raise ValueError('hd_images must be fed to fetch loss / trainer / hd_images')
+            if want_train:
+                loss = self.train_step(sd, hd, float(lr))
+                sr = self.stack.acts[-1]
+            else:
+                sr = self.stack.forward(sd, keep=True)
+                if want_loss:
+                    loss = self.stack.loss
+                    ops.mse_fwd_bwd(sr, hd, loss, accumulate=False, want_grad=False)
+                    self.stack.add_regulariser_loss()
         out = {}
         taps = None
         for k in keys:

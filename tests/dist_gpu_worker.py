@@ -1,0 +1,70 @@
+"""One rank of the data-parallel GPU rehearsal (started by tests/test_gpu_dist.py as a fresh child process).
+
+Builds the REAL model (VdsrModel on libsrx.so), attaches dist.py's gradient exchange, runs `steps` train steps on
+its shard of a seeded global batch and saves its parameters / optimizer slots / averaged gradient.  With
+SRX_DIST_BACKEND=gloo several ranks share one GPU (RCCL needs a GPU per rank), which exercises everything of the
+N > 1 path except the RCCL transport itself.
+
+  python tests/dist_gpu_worker.py OUT_DIR USE_ADAM STEPS LAYERS GLOBAL_BATCH
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def global_batch(n, size=41, seed=7):
+    rng = np.random.default_rng(seed)
+    hd = rng.uniform(-1, 1, (n, size, size, 3)).astype(np.float32)
+    sd = np.clip(hd + 0.1 * rng.normal(size=hd.shape), -1, 1).astype(np.float32)
+    return sd, hd
+
+
+def run(out_dir, use_adam, steps, layers, n_global, lr):
+    from ml_super_resolution_amd import dist as srx_dist
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        srx_dist.init_process_group(rank, world, local_rank)
+    # every rank but 0 starts from different weights and a different step count: attach() must fix both
+    model = model_vdsr.VdsrModel(num_layers=layers, use_adam=use_adam, device=dev, seed=11 + 100 * rank)
+    model.stack.global_step = 5 * rank
+    if world > 1:
+        srx_dist.attach(model.stack, world, timed=True)
+    sd, hd = global_batch(n_global)
+    sd, hd = torch.from_numpy(sd).to(dev), torch.from_numpy(hd).to(dev)
+    if world > 1:
+        sd, hd = srx_dist.shard(sd, rank, world).contiguous(), srx_dist.shard(hd, rank, world).contiguous()
+    losses = []
+    first_grad = None
+    for s in range(steps):
+        loss = model.train_step(sd, hd, lr)
+        losses.append(float(loss.item()))
+        if s == 0:
+            first_grad = model.stack.grads.detach().cpu().numpy().copy()
+    torch.cuda.synchronize()
+    out = {'params': model.stack.params.detach().cpu().numpy(), 'first_grad': first_grad,
+           'opt_m': model.stack.opt_m.detach().cpu().numpy(), 'losses': np.asarray(losses),
+           'global_step': np.int64(model.stack.global_step)}
+    if model.stack.opt_v is not None:
+        out['opt_v'] = model.stack.opt_v.detach().cpu().numpy()
+    if world > 1:
+        out['allreduce_ms'] = np.float64(srx_dist.allreduce_ms(model.stack))
+        out['n_hook_calls'] = np.int64(len(model.stack.allreduce_events))
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **out)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    run(sys.argv[1], sys.argv[2] == '1', int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]))

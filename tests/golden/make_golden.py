@@ -74,6 +74,36 @@ def make_pins():
         arr = np.asarray(Image.open(os.path.join(ASSETS, 'vdsr-fig2-%s.png' % name)).convert('RGB'))
         crops[name.replace('.', '_')] = arr[80:176, 80:176].copy()
     np.savez_compressed(os.path.join(HERE, 'pin_p3_crop.npz'), **crops)
+    make_pin_p5()
+
+
+P5_CROP = (60, 108, 70, 134)     # rows y0:y1, columns x0:x1 of the 224x224 source (eagle's head)
+
+
+def make_pin_p5():
+    """P5: the only end-to-end BYTE pin the reference offers.  assets/enet_eagle_bq.png is the `_bq.png` the
+    reference's enet/enet/experiment_resolve.py:61-147 wrote for assets/enet_eagle.png: scipy.misc.imresize(image,
+    400, 'bicubic') -> / 127.5 - 1 -> saturate_cast(x * 127.5 + 127.5, uint8) -> PNG.  PIL's bicubic x4 of the source
+    reproduces it with 0 differing bytes (checked here on the whole image; both digests go to pins.json), which pins
+    (a) imresize == PIL bicubic and (b) that the float round trip is the identity on bytes (multiply and add rounded
+    separately).  The fixture keeps a crop of the source and the matching x4 region of the reference's output."""
+    from PIL import Image
+    src = Image.open(os.path.join(ASSETS, 'enet_eagle.png')).convert('RGB')
+    ref = np.asarray(Image.open(os.path.join(ASSETS, 'enet_eagle_bq.png')).convert('RGB'))
+    mine = np.asarray(src.resize((src.width * 4, src.height * 4), Image.BICUBIC))
+    y0, y1, x0, x1 = P5_CROP
+    np.savez_compressed(os.path.join(HERE, 'pin_p5_eagle_crop.npz'),
+                        source=np.asarray(src)[y0:y1, x0:x1].copy(),
+                        reference_bq=ref[4 * y0:4 * y1, 4 * x0:4 * x1].copy(), crop=np.asarray(P5_CROP))
+    path = os.path.join(HERE, 'pins.json')
+    pins = json.load(open(path))
+    pins['P5'] = {'source': 'assets/enet_eagle.png', 'reference_output': 'assets/enet_eagle_bq.png',
+                  'source_size': list(src.size), 'output_shape': list(ref.shape),
+                  'reference_bq_pixels_sha256': hashlib.sha256(ref.tobytes()).hexdigest(),
+                  'pil_bicubic_x4_pixels_sha256': hashlib.sha256(mine.tobytes()).hexdigest(),
+                  'differing_bytes_whole_image': int((ref != mine).sum())}
+    with open(path, 'w') as f:
+        json.dump(pins, f, indent=1, sort_keys=True)
 
 
 def make_ops():

@@ -1,0 +1,114 @@
+"""Data parallelism on the REAL engine: two fresh child processes share the one GPU of the box, each
+builds VdsrModel on libsrx.so, attaches dist.py's exchange (gloo: RCCL needs one GPU per rank) and takes two
+train steps on its half of a global batch.  Required: both ranks end with bit-identical parameters, and those
+equal one process stepping the concatenated batch -- for Adam and for the Momentum + clip path (clip AFTER the
+reduce, vdsr/vdsr/model_vdsr.py:170-181 applied to the averaged gradient).  Also: `python bench.py --gpus 2`
+started bare launches its own ranks and prints one valid line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'dist_gpu_worker.py')
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(out_dir, world, args, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), SRX_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, WORKER, str(out_dir)] + [str(a) for a in args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors='replace'))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, 'rank %d failed:\n%s' % (r, outs[r][-3000:])
+    return [np.load(os.path.join(str(out_dir), 'rank%d.npz' % r)) for r in range(world)]
+
+
+def _single(out_dir, args):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    subprocess.check_call([sys.executable, WORKER, str(out_dir)] + [str(a) for a in args], env=env)
+    return np.load(os.path.join(str(out_dir), 'rank0.npz'))
+
+
+@pytest.mark.parametrize('use_adam', [1, 0], ids=['adam', 'momentum_clip'])
+def test_two_ranks_equal_single_process(tmp_path, use_adam):
+    steps, layers, n_global = 2, 6, 8
+    # momentum path: the gradients of this problem reach ~7e-3 (bias of the last layer); lr 4 puts the clip bound
+    # 0.01/lr = 2.5e-3 inside their range, so that clipping before the reduce (wrong) and after it (right) differ
+    lr = 5e-5 if use_adam else 4.0
+    args = [use_adam, steps, layers, n_global, lr]
+    d2 = tmp_path / 'w2'
+    d2.mkdir()
+    r0, r1 = _run_ranks(d2, 2, args)
+    d1 = tmp_path / 'w1'
+    d1.mkdir()
+    one = _single(d1, args)                         # same seed as rank 0, whole batch, no hook
+
+    # replicas: identical bit for bit, same step count (rank 1 started from other weights and step 5)
+    assert int(r0['global_step']) == int(r1['global_step']) == steps
+    for key in ('params', 'opt_m', 'first_grad') + (('opt_v',) if use_adam else ()):
+        np.testing.assert_array_equal(r0[key], r1[key], err_msg=key)
+    assert int(r0['n_hook_calls']) == steps and float(r0['allreduce_ms']) > 0.0
+
+    # the averaged gradient of the two half batches == the gradient of the whole batch
+    g, gref = r0['first_grad'], one['first_grad']
+    gmax = np.abs(gref).max()
+    assert np.abs(g - gref).max() <= 2e-6 * gmax, np.abs(g - gref).max() / gmax
+    if not use_adam:
+        cap = 0.01 / lr
+        assert np.abs(gref).max() > cap, 'test must exercise the clip'
+    # parameters after two optimizer steps
+    p, pref = r0['params'], one['params']
+    pmax = np.abs(pref).max()
+    if use_adam:
+        # Adam divides by sqrt(v)+eps: where |g| is of the order of eps=1e-8 the update amplifies the rounding
+        # difference of the two summation orders; everywhere else the bound is 1e-6 of the largest parameter
+        big = np.abs(gref) > 1e-5 * gmax
+        assert np.abs(p - pref)[big].max() <= 1e-6 * pmax
+        assert np.abs(p - pref).max() <= 2 * steps * lr       # no element can move further than lr per step
+    else:
+        # linear in the (clipped) gradient: the rounding difference of the gradients times lr per step
+        assert np.abs(p - pref).max() <= 1e-6 * pmax + steps * lr * 2e-6 * gmax
+    # the loss of step 1 is the local mean: the mean over ranks is the global one
+    np.testing.assert_allclose(0.5 * (r0['losses'][0] + r1['losses'][0]), one['losses'][0], rtol=2e-6)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two fresh ranks (gloo on a
+    one-GPU box), rank 0 prints ONE JSON line with the contract's keys."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
+                          '1', '--no-extras'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode(errors='replace')[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['global_batch'] == 512
+    assert line['value'] > 0 and line['allreduce_ms'] > 0
+    assert line['roofline']['frac'] > 0

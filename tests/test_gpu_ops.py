@@ -10,6 +10,13 @@ from tests.golden.make_golden import OP_CASES
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-3
+# What the design delivers (exact-fp32 fmaf chains against a float64 oracle), asserted element by element beside
+# the north star's 1e-3: |err| <= ATOL_SCALE * max|ref| + RTOL_ELEM * |ref|.  The max-norm bound alone would let a
+# wrong halo pixel in a low-magnitude region through.  Envelope measured on MI355X over the whole suite (the
+# largest ratio err / bound seen is appended to gpurun_out/close_envelope.txt when that directory exists).
+ATOL_SCALE = 1e-5
+RTOL_ELEM = 1e-4
+_envelope = {'worst': 0.0}
 
 
 def dev(a):
@@ -25,6 +32,18 @@ def close(got, ref, rtol=RTOL):
     err = np.abs(got - ref).max()
     assert np.isfinite(got).all()
     assert err <= rtol * scale, 'max err %.3e vs scale %.3e' % (err, scale)
+    if rtol > RTOL:          # a caller that asks for a looser bound (sampled full-size checks) opts out
+        return
+    bound = ATOL_SCALE * scale + RTOL_ELEM * np.abs(ref)
+    ratio = float((np.abs(got - ref) / bound).max())
+    if ratio > _envelope['worst']:
+        _envelope['worst'] = ratio
+        import os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        if os.path.isdir(out):
+            with open(os.path.join(out, 'close_envelope.txt'), 'a') as f:
+                f.write('%.4f of the elementwise bound (max-norm err %.3e of scale)\n' % (ratio, err / scale))
+    assert ratio <= 1.0, 'elementwise: err reaches %.2f x (%.0e * max|ref| + %.0e * |ref|)' % (ratio, ATOL_SCALE, RTOL_ELEM)
 
 
 @pytest.fixture(scope='module')

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: variable fetches without feeds, checkpoint naming / state file / beta powers,
+flag parsing, and the C ABI's threading promise (TSan build of the host code)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_step_and_learning_rate_fetch_need_no_feed():
+    """`step = session.run(model['step'])` is the first line of the reference's loops
+    (vdsr/vdsr/experiment_train.py:126, espcn/espcn/experiment_train.py:92): no placeholder is fed."""
+    from ml_super_resolution_amd import graph
+    from ml_super_resolution_amd.espcn import model_espcn
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    sd, hd = graph.placeholder(name='sd'), graph.placeholder(name='hd')
+    model = model_vdsr.build_model(sd, hd, num_layers=3, use_adam=True, device='cpu', seed=0)
+    with graph.Session() as session:
+        assert session.run(model['step']) == 0
+        assert session.run(model['learning_rate']) == pytest.approx(0.1)        # model_vdsr.py:136-141
+        assert session.run({'s': model['step']}, feed_dict={model['learning_rate']: 0.01}) == {'s': 0}
+        with pytest.raises(ValueError, match='sd_images must be fed'):
+            session.run(model['sr_images'])
+        with pytest.raises(ValueError, match='sd_images must be fed'):
+            session.run([model['step'], model['loss']])
+    lr_src, hr_t = graph.placeholder(name='lr'), graph.placeholder(name='hr')
+    em = model_espcn.build_model(lr_src, 3, hr_t, device='cpu', seed=0)
+    with graph.Session() as session:
+        assert session.run(em['step']) == 0
+        with pytest.raises(ValueError, match='lr_source must be fed'):
+            session.run(em['sr_result'])
+
+
+def test_tf_checkpoint_names_state_file_and_beta_powers(tmp_path):
+    from ml_super_resolution_amd import tf_bundle
+    from ml_super_resolution_amd.engine import ConvStack
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    stack = ConvStack(model_vdsr.layer_specs(3), device='cpu', residual=True, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(0)
+    stack.params.copy_(torch.randn(stack.flat_size, generator=g))
+    stack.opt_m = torch.randn(stack.flat_size, generator=g)
+    stack.opt_v = torch.rand(stack.flat_size, generator=g)
+    stack.global_step = 7
+    d = tmp_path / 'ckpt'
+    d.mkdir()
+    assert tf_bundle.latest_checkpoint(str(d)) is None
+    stack.save_tf_checkpoint(str(d / 'model.ckpt-7'), extra={'learning_rate': np.float32(0.1)})
+    vals = tf_bundle.load_checkpoint(str(d / 'model.ckpt-7'))
+    # every global variable of the reference's graph: 3 x (kernel, bias) x (value, Adam, Adam_1) + beta powers +
+    # global_step + learning_rate (vdsr/vdsr/model_vdsr.py:136-147)
+    assert len(vals) == 3 * 2 * 3 + 4
+    for key in ('conv2d/kernel', 'conv2d_1/bias', 'conv2d_2/kernel/Adam', 'conv2d_2/bias/Adam_1', 'learning_rate'):
+        assert key in vals
+    # TF's AdamOptimizer starts the powers at beta and multiplies once per step: beta ** (N + 1)
+    np.testing.assert_allclose(vals['beta1_power'], 0.9 ** 8, rtol=1e-6)
+    np.testing.assert_allclose(vals['beta2_power'], 0.999 ** 8, rtol=1e-6)
+    assert vals['global_step'].dtype == np.int64 and int(vals['global_step']) == 7
+    # the `checkpoint` state file (what tf.train.latest_checkpoint reads, experiment_train.py:108)
+    text = open(str(d / 'checkpoint')).read()
+    assert text == 'model_checkpoint_path: "model.ckpt-7"\nall_model_checkpoint_paths: "model.ckpt-7"\n'
+    stack.global_step = 9
+    stack.save_tf_checkpoint(str(d / 'model.ckpt-9'))
+    text = open(str(d / 'checkpoint')).read().splitlines()
+    assert text[0] == 'model_checkpoint_path: "model.ckpt-9"'
+    assert text[1:] == ['all_model_checkpoint_paths: "model.ckpt-7"', 'all_model_checkpoint_paths: "model.ckpt-9"']
+    assert tf_bundle.latest_checkpoint(str(d)) == str(d / 'model.ckpt-9')
+    # restore: weights, slots, step
+    other = ConvStack(model_vdsr.layer_specs(3), device='cpu', residual=True, weight_decay=1e-4)
+    other.load_tf_checkpoint(str(d / 'model.ckpt-7'))
+    assert other.global_step == 7
+    for i in range(3):          # (the flat buffers' alignment padding is not part of any variable)
+        for buf_a, buf_b in ((None, None), (other.opt_m, stack.opt_m), (other.opt_v, stack.opt_v)):
+            assert torch.equal(other.kernel(i, buf_a), stack.kernel(i, buf_b))
+            assert torch.equal(other.bias(i, buf_a), stack.bias(i, buf_b))
+
+
+def test_use_adam_flag_forms():
+    """tf.app.flags booleans: bare `--use_adam` (vdsr/makefile:26), `--use_adam=false`, `--use_adam false`."""
+    from ml_super_resolution_amd.vdsr.experiment_train import parse_flags
+    assert parse_flags([]).use_adam is True
+    assert parse_flags(['--use_adam']).use_adam is True
+    assert parse_flags(['--use_adam', '--batch_size', '8']).batch_size == 8
+    assert parse_flags(['--use_adam=false']).use_adam is False
+    assert parse_flags(['--use_adam', 'False']).use_adam is False
+
+
+def test_forward_buffers_do_not_pile_up_per_image_size():
+    """keep=False temporaries are keyed by (parity, channels): a new image size replaces the old buffers."""
+    from ml_super_resolution_amd.engine import ConvStack
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    stack = ConvStack(model_vdsr.layer_specs(6), device='cpu', residual=True)
+    shapes = stack._shapes((1, 30, 20, 3))
+    for i, s in enumerate(stack.specs):
+        stack._buf(('tmp', i & 1, s.cout), shapes[i])
+    n = len(stack._bufs)
+    for hw in ((31, 21), (50, 60), (8, 8)):
+        shapes = stack._shapes((1,) + hw + (3,))
+        for i, s in enumerate(stack.specs):
+            stack._buf(('tmp', i & 1, s.cout), shapes[i])
+    assert len(stack._bufs) == n == 3
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+def test_abi_host_code_is_thread_safe_under_tsan(tmp_path):
+    """include/srx.h promises concurrent calls from several host threads.  The host side of srx_api.hip is built
+    with ThreadSanitizer (CPU build only: the kernel launchers are stubbed out) and two threads hammer
+    srx_conv2d_workspace_bytes / srx_set_conv_path / a failing srx_conv2d_fwd (thread-local error text)."""
+    exe = str(tmp_path / 'tsan_abi')
+    csrc = os.path.join(ROOT, 'ml_super_resolution_amd', 'csrc')
+    cmd = ['/opt/rocm/bin/hipcc', '-O1', '-g', '-std=c++17', '-fsanitize=thread', '--cuda-host-only', '--offload-arch=gfx950',
+           '-Wno-unused-result', os.path.join(csrc, 'srx_api.hip'), '-x', 'hip', os.path.join(ROOT, 'tests', 'tsan_abi_driver.cpp'),
+           '-o', exe, '-lpthread']
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert build.returncode == 0, build.stdout.decode(errors='replace')[-4000:]
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                         env=dict(os.environ, TSAN_OPTIONS='halt_on_error=1 exitcode=66'))
+    out = run.stdout.decode(errors='replace')
+    assert run.returncode == 0 and 'ThreadSanitizer' not in out and 'tsan driver ok' in out, out[-4000:]

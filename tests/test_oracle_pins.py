@@ -85,3 +85,32 @@ def test_p4_srcnn_panel_geometry():
     side, size = O.srcnn_sanity_check(256)
     out = size - (9 - 1) - (1 - 1) - (5 - 1)
     assert pins['P4'] == {'width': 3 * out, 'height': out}
+
+
+P5_MARGIN = 12      # HR pixels: bicubic support is 2 source pixels (8 HR) either side; the crop's border rows / columns
+                    # see the crop's edge instead of the neighbouring pixels of the whole image
+
+
+def test_p5_bicubic_bq_png_bytes():
+    """The only end-to-end BYTE pin the reference holds: assets/enet_eagle_bq.png is what
+    enet/enet/experiment_resolve.py:61-147 wrote for assets/enet_eagle.png
+    (scipy.misc.imresize(image, 400, 'bicubic') -> / 127.5 - 1 -> saturate_cast(x * 127.5 + 127.5) -> PNG).
+    Whole image: digests recorded at fixture time agree (0 differing bytes).  Committed crop: PIL bicubic x4 of the
+    source crop == the reference's bytes away from the crop border, and the oracle's float round trip + truncating
+    encode is the identity on them."""
+    from PIL import Image
+    pins = json.load(open(os.path.join(GOLDEN, 'pins.json')))['P5']
+    assert pins['differing_bytes_whole_image'] == 0
+    assert pins['reference_bq_pixels_sha256'] == pins['pil_bicubic_x4_pixels_sha256']
+    z = np.load(os.path.join(GOLDEN, 'pin_p5_eagle_crop.npz'))
+    src, ref = z['source'], z['reference_bq']
+    assert ref.shape == (src.shape[0] * 4, src.shape[1] * 4, 3)
+    bq = np.asarray(Image.fromarray(src).resize((src.shape[1] * 4, src.shape[0] * 4), Image.BICUBIC))
+    m = P5_MARGIN
+    np.testing.assert_array_equal(bq[m:-m, m:-m], ref[m:-m, m:-m])
+    # the reference feeds bq / 127.5 - 1 and encodes saturate_cast(x * 127.5 + 127.5): identity on bytes
+    x = ref.astype(np.float32) / np.float32(127.5) - np.float32(1.0)
+    np.testing.assert_array_equal(O.saturate_u8(x), ref)
+    # (a fused multiply-add would NOT be: it rounds once and moves bytes by one level)
+    fused = np.floor(np.clip(x.astype(np.float64) * 127.5 + 127.5, 0, 255)).astype(np.uint8)
+    assert (fused != ref).any()
