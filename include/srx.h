@@ -59,6 +59,12 @@ typedef struct {
     int32_t act;           /* srx_act fused after bias */
     int32_t post_add_relu; /* relu after the skip add: enet/enet/model_enet.py:8-31 */
     int32_t precision;     /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32); the only mode */
+    int32_t subpixel_r;    /* srx_conv2d_fwd only.  0 / 1: y is [N,OH,OW,Cout].  r > 1: the epilogue stores through the
+                            * sub-pixel (depth-to-space) index map, y is [N,OH*r,OW*r,Cout/(r*r)]:
+                            *   y[n, h*r+dy, w*r+dx, c] = conv[n, h, w, (dy*r+dx)*C + c]
+                            * bit-identical to srx_conv2d_fwd followed by srx_depth_to_space, without the intermediate
+                            * tensor (ESPCN's f3 layer + espcn/espcn/experiment_test.py:171-177 in one launch).
+                            * Ignored (must be 0 or 1) by the backward entry points. */
 } srx_conv_desc;
 
 const char* srx_version(void);

@@ -35,7 +35,7 @@ class SrxError(RuntimeError):
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_mode', 'act',
-                 'post_add_relu', 'precision')]
+                 'post_add_relu', 'precision', 'subpixel_r')]
 
 
 _lib = None

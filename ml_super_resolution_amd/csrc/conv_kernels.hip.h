@@ -51,6 +51,8 @@ struct ConvArgs {
     int* tile_counter;    // dynamic scheduling (two-workgroup kernels): next tile to hand out, preset to gridDim.x; null = static
     int tiles_total, tiles_per_col;   // N*NTX*tiles_per_col tiles of TH rows (the last of a column may be shorter)
     int lds_sched_slot;   // float index in LDS of the 4-byte mailbox used to broadcast the tile index
+    int d2s_r, d2s_rc;    // sub-pixel store mode (two-workgroup kernels): r > 1 -> y is [N,OH*r,OW*r,Cout/(r*r)] and channel
+                          // ch of LR pixel (h,w) is stored at HR row h*r + ch/rc, column offset w*rc + ch%rc, rc = r*C
 };
 
 struct WgradArgs {
@@ -273,6 +275,18 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4
         // ragged channel counts (Cout = 3, 27, ...): scalar tail
         const float* sk = (AUX && a.skip) ? a.skip + img_base : nullptr;
         const float* mk = (AUX && a.mask) ? a.mask + img_base : nullptr;
+        // Sub-pixel store mode (espcn/espcn/experiment_test.py:171-177 fused into the f3 layer): channel ch of an LR
+        // pixel goes to HR row +ch/rc, element +ch%rc of the pixel's r*C-float segment.  The lane's four channels are
+        // the same for the whole kernel, so these are four small constants (host: no skip / mask in this mode).
+        int eo[4] = {0, 1, 2, 3};
+        if (a.d2s_r) {
+            const int hr_row = a.OW * a.d2s_rc;      // floats per HR row: OW*r pixels of C channels
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = cb + e, dy = ch / a.d2s_rc;
+                eo[e] = dy * hr_row + (ch - dy * a.d2s_rc);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             if (!valid[i]) continue;
@@ -284,7 +298,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4
                     if (sk) t += sk[off[i] + e];
                     if (AUX && a.post_relu) t = fmaxf(t, 0.f);
                     if (mk) t *= act_grad_from_y(mk[off[i] + e], a.mask_act);
-                    yb[off[i] + e] = t;
+                    yb[off[i] + eo[e]] = t;
                 }
             }
         }
@@ -465,7 +479,7 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
     const unsigned long long ts_pro = SRX_STAMP();
     const int npx = th * tw;
     const int cb = cout0 + 4 * kq;
-    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout) && !a.d2s_r;
     const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;   // wave-uniform
     int laddr[G];       // float index of this lane's pixel (tap 0,0) in LDS
     unsigned off[G];    // element offset of this lane's 4 output channels inside image n
@@ -480,7 +494,10 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
         const int orow = fdiv_small(tt, inv_tw, tw);
         const int ocol = tt - orow * tw;
         laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
-        off[i] = valid[i] ? (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb) : 0u;
+        // (sub-pixel store mode: the offset of HR pixel (h*r, w*r), channel 0 -- conv_epilogue adds the channel part)
+        off[i] = !valid[i] ? 0u
+                 : (a.d2s_r ? (unsigned)(((h + orow) * a.d2s_r * a.OW + ow0 + ocol) * a.d2s_rc)
+                            : (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb));
         acc[i] = bias4;
     }
     f32x4 aux[G];
@@ -1390,7 +1407,7 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
     const int TAPS = KH * KW;
     const int npx = th * tw;
     const int cb = cout0 + 4 * kq;
-    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout);
+    const bool vec = ((a.Cout & 3) == 0) && (cb + 3 < a.Cout) && !a.d2s_r;
     const size_t img_base = (size_t)n * a.OH * a.OW * a.Cout;   // wave-uniform
     int laddr[G];       // float index of this lane's pixel (tap 0,0) in LDS
     unsigned off[G];    // element offset of this lane's 4 output channels inside image n
@@ -1404,7 +1421,10 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
         const int orow = fdiv_small(tt, inv_tw, tw);
         const int ocol = tt - orow * tw;
         laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
-        off[i] = valid[i] ? (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb) : 0u;
+        // (sub-pixel store mode: the offset of HR pixel (h*r, w*r), channel 0 -- conv_epilogue adds the channel part)
+        off[i] = !valid[i] ? 0u
+                 : (a.d2s_r ? (unsigned)(((h + orow) * a.d2s_r * a.OW + ow0 + ocol) * a.d2s_rc)
+                            : (unsigned)(((h + orow) * a.OW + ow0 + ocol) * a.Cout + cb));
         acc[i] = bias4;
     }
     f32x4 aux[G];

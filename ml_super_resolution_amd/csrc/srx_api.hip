@@ -191,6 +191,9 @@ int check_desc(const srx_conv_desc* d) {
     if (d->pad_mode != SRX_PAD_SAME && d->pad_mode != SRX_PAD_VALID) return fail(SRX_ERR_BAD_ARG, "bad pad_mode");
     if (d->act < SRX_ACT_NONE || d->act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad activation");
     if (d->precision != 0) return fail(SRX_ERR_UNSUPPORTED, "precision mode %d not implemented", d->precision);
+    if (d->subpixel_r < 0 || d->subpixel_r > 16) return fail(SRX_ERR_BAD_ARG, "bad subpixel_r %d", d->subpixel_r);
+    if (d->subpixel_r > 1 && d->Cout % (d->subpixel_r * d->subpixel_r))
+        return fail(SRX_ERR_BAD_ARG, "subpixel_r %d: Cout %d is not a multiple of r*r", d->subpixel_r, d->Cout);
     if (d->pad_mode == SRX_PAD_VALID && (d->H < d->KH || d->W < d->KW))
         return fail(SRX_ERR_BAD_ARG, "VALID convolution with input smaller than the filter");
     if ((long)d->H * d->W * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1L << 31))
@@ -227,7 +230,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // mirror case, 3 -> 64 channels, was tried the same way and lost to the MFMA kernel: 56 vs 48 us.)
     // SRX_NARROW=0 keeps them on the MFMA kernels (A/B).
     {
-        if (knobs().narrow && launch_conv_narrow(k, a, s, &err)) {
+        if (knobs().narrow && !a.d2s_r && launch_conv_narrow(k, a, s, &err)) {
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
@@ -241,12 +244,12 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
                         (!a.mask || (a.mask_act == ACT_RELU && a.act == ACT_NONE && !a.post_relu));
     // (p.RS == W + pad_l: the only pad slots of a tile row are the pad_l leading ones, which the scalar staging
     // never writes; a dgrad of a VALID layer has trailing pad slots inside the row as well and stays on path 0)
-    const bool pipe_ok = epi_ok && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
+    const bool pipe_ok = epi_ok && !a.d2s_r && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
                          16 * npart <= a.OW && (a.Cout & 3) == 0 &&
                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     // Column-strip variant (images too wide for full-width tiles): strips of 16 or 32 columns no wider than the
     // image, one sub-tile sequence per workgroup (64 output channels); any padding.
-    const bool strip_ok = epi_ok && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
+    const bool strip_ok = epi_ok && !a.d2s_r && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
                           p.RS >= ppp && npart == 1 && (a.Cout & 3) == 0 &&
                           a.y != a.skip && a.y != a.mask &&   // (the columns two strips share are computed twice: no in-place epilogue operand)
                           (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
@@ -360,6 +363,12 @@ int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const
     a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.mask = nullptr; a.y = y;
     fill_conv_args(&a, p, d->N, d->H, d->W, d->Cin, d->Cout);
     a.act = d->act; a.post_relu = d->post_add_relu; a.mask_act = 0;
+    if (d->subpixel_r > 1) {
+        // the store goes through the depth-to-space map: y is [N, OH*r, OW*r, Cout/(r*r)]
+        if (skip) return fail(SRX_ERR_UNSUPPORTED, "subpixel_r with a skip operand is not implemented");
+        a.d2s_r = d->subpixel_r;
+        a.d2s_rc = d->Cout / d->subpixel_r;
+    }
     return dispatch_conv(p, false, a, (hipStream_t)stream, ws, ws_bytes);
 }
 

@@ -9,10 +9,14 @@ model_espcn.py -- mirror of espcn/espcn/model_espcn.py (reference) on the MI355X
 
 Network (model_espcn.py:30-62 / :117-134): 5x5 conv -> 64 tanh, 3x3 -> 32 tanh, 3x3 -> 3*r*r linear,
 all SAME.  `sr_result` stays in sub-pixel space [N,H,W,3*r*r], exactly like the reference; the
-depth-to-space map is a separate op (ops.depth_to_space == experiment_test.py:171-177).
+depth-to-space map (experiment_test.py:171-177) is either the separate op ops.depth_to_space or -- on the
+inference path `super_resolve` -- the STORE MODE of the f3 layer (srx_conv_desc.subpixel_r): three launches,
+no intermediate sub-pixel tensor, replayed as one HIP graph per input shape.
 Checkpoints: the reference restores a TF bundle + .meta graph; here a checkpoint is an .npz of the
 same variable names (`f1/kernel:0` ...), `meta_path` is accepted and ignored.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -35,15 +39,67 @@ class EspcnModel(object):
         for i in range(3):
             truncated_normal_(self.stack.kernel(i), 0.02, gen)      # model_espcn.py:21; biases zero
         self.placeholders = {}
+        # inference path: HIP-graph replay of the three launches (SRX_ESPCN_GRAPH=0: eager launches)
+        self.use_graph = os.environ.get('SRX_ESPCN_GRAPH', '1') != '0'
+        self._graphs = {}
+        self.inference_path = 'f1, f2, f3 with the sub-pixel store fused into its epilogue: 3 launches, no standalone ' \
+                              'depth-to-space pass' + (', replayed as one HIP graph' if self.use_graph else ', eager')
 
     # ---- eager API -----------------------------------------------------------------------------
     def forward(self, lr_source, keep=False):
         """sr_result in sub-pixel space [N,H,W,3*r*r]."""
         return self.stack.forward(lr_source, keep=keep)
 
-    def super_resolve(self, lr_source):
-        """forward + depth-to-space: [N,H,W,3] -> [N,H*r,W*r,3]."""
+    def super_resolve_two_step(self, lr_source):
+        """forward + the standalone depth-to-space pass (4 launches): [N,H,W,3] -> [N,H*r,W*r,3]."""
         return ops.depth_to_space(self.forward(lr_source), self.scaling_factor)
+
+    def _super_resolve_launches(self, lr_source, out=None):
+        st, r = self.stack, self.scaling_factor
+        n, h, w, _ = lr_source.shape
+        t = ops.conv2d_fwd(lr_source, st.kernel(0), st.bias(0), 'same', 'tanh', out=st._buf(('sr', 0), (n, h, w, 64)))
+        t = ops.conv2d_fwd(t, st.kernel(1), st.bias(1), 'same', 'tanh', out=st._buf(('sr', 1), (n, h, w, 32)))
+        return ops.conv2d_fwd(t, st.kernel(2), st.bias(2), 'same', None, subpixel_r=r,
+                              out=out if out is not None else st._buf(('sr', 2), (n, h * r, w * r, 3)))
+
+    def super_resolve(self, lr_source, use_graph=None):
+        """The inference path (espcn/espcn/experiment_test.py:156-181: run the net, then the sub-pixel shuffle):
+        [N,H,W,3] -> [N,H*r,W*r,3] in three launches -- the f3 layer stores straight through the depth-to-space map
+        (bit-identical to super_resolve_two_step) -- replayed as ONE HIP graph per input shape: the problem is
+        launch-latency-bound (0.57 GFLOP at BASELINE configs[1]).  The returned tensor is a buffer owned by the
+        model and overwritten by the next call."""
+        if not (self.use_graph if use_graph is None else use_graph) or not lr_source.is_cuda:
+            return self._super_resolve_launches(lr_source)
+        key = tuple(lr_source.shape)
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(lr_source)
+        static_in, graph_obj, out = g
+        if lr_source.data_ptr() != static_in.data_ptr():
+            static_in.copy_(lr_source)
+        graph_obj.replay()
+        return out
+
+    def _capture(self, lr_source):
+        """Warm the kernels up on a side stream (function attributes and buffers must exist before capture),
+        then record the three launches.  The graph reads the weights through their pointers: training steps or
+        load_variables() that update them in place are seen by later replays."""
+        if len(self._graphs) >= 8:                      # a directory of images of many sizes: keep the cache small
+            self._graphs.pop(next(iter(self._graphs)))
+        static_in = lr_source.clone()
+        n, h, w, _ = lr_source.shape
+        r = self.scaling_factor
+        out = torch.empty((n, h * r, w * r, 3), dtype=torch.float32, device=lr_source.device)
+        side = torch.cuda.Stream(device=lr_source.device)
+        side.wait_stream(torch.cuda.current_stream(lr_source.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._super_resolve_launches(static_in, out=out)
+        torch.cuda.current_stream(lr_source.device).wait_stream(side)
+        graph_obj = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_obj):
+            self._super_resolve_launches(static_in, out=out)
+        return static_in, graph_obj, out
 
     def train_step(self, lr_source, hr_target, learning_rate):
         """MSE in sub-pixel space (hr_target is the space-to-depth label, dataset.py:140-156) + Adam

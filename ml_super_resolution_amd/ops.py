@@ -27,13 +27,13 @@ def _chk(t, name):
         raise ValueError('%s lives on %s but the current device is cuda:%d' % (name, t.device, torch.cuda.current_device()))
 
 
-def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False):
+def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False, subpixel_r=0):
     N, H, W, Cin = x_shape
     KH, KW, wci, Cout = w_shape
     if wci != Cin:
         raise ValueError('filter Cin %d != input channels %d' % (wci, Cin))
     return ConvDesc(N, H, W, Cin, Cout, KH, KW, 1, PAD_BY_NAME[padding.lower()],
-                    ACT_BY_NAME[act] if not isinstance(act, int) else act, int(post_add_relu), 0)
+                    ACT_BY_NAME[act] if not isinstance(act, int) else act, int(post_add_relu), 0, int(subpixel_r))
 
 
 def out_shape(d):
@@ -63,12 +63,21 @@ def reduce_scratch(device):
     return _scratch[key]
 
 
-def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_relu=False, out=None):
-    """act(bias + x (*) w) [+ skip] [relu] -- srx_conv2d_fwd."""
+def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_relu=False, out=None, subpixel_r=0):
+    """act(bias + x (*) w) [+ skip] [relu] -- srx_conv2d_fwd.  subpixel_r > 1: the result is stored through the
+    depth-to-space map, [N,OH*r,OW*r,Cout/r^2] (bit-identical to conv2d_fwd + depth_to_space, one launch)."""
     for t, n in ((x, 'x'), (w, 'w'), (bias, 'bias'), (skip, 'skip')):
         _chk(t, n)
-    d = conv_desc(x.shape, w.shape, padding, act, post_add_relu)
-    y = out if out is not None else torch.empty(out_shape(d), dtype=torch.float32, device=x.device)
+    d = conv_desc(x.shape, w.shape, padding, act, post_add_relu, subpixel_r)
+    shape = out_shape(d)
+    if subpixel_r > 1:
+        r = int(subpixel_r)
+        if shape[3] % (r * r):
+            raise ValueError('subpixel_r %d: %d output channels are not a multiple of r*r' % (r, shape[3]))
+        shape = (shape[0], shape[1] * r, shape[2] * r, shape[3] // (r * r))
+    if out is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError('out has shape %s, expected %s' % (tuple(out.shape), tuple(shape)))
+    y = out if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
     ws = sched_workspace(x.device)
     check(lib().srx_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(skip), _ptr(y),
                                ctypes.c_void_p(ws.data_ptr()), 256, _stream()), 'srx_conv2d_fwd')

@@ -15,24 +15,17 @@ def timeit(fn, iters=200):
     for _ in range(iters): fn()
     e.record(); e.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-t_eager = timeit(lambda: m.super_resolve(x))
 hr_px = 32 * 51 * 51
-line = 'ESPCN 3x, batch 32x17x17: eager %.1f us (%.1f HR-MP/s)' % (t_eager, hr_px / t_eager)
-try:
-    g = torch.cuda.CUDAGraph()
-    sside = torch.cuda.Stream()
-    with torch.cuda.stream(sside):
-        for _ in range(3): y = m.super_resolve(x)
-        torch.cuda.current_stream().synchronize()
-        with torch.cuda.graph(g, stream=sside):
-            y = m.super_resolve(x)
-    t_graph = timeit(lambda: g.replay())
-    ref = m.super_resolve(x)
-    g.replay(); torch.cuda.synchronize()
-    line += ' | HIP graph replay %.1f us (%.1f HR-MP/s) equal=%s' % (t_graph, hr_px / t_graph, bool(torch.equal(ref, y)))
-except Exception as exc:
-    line += ' | graph capture failed: %r' % (exc,)
+t_two = timeit(lambda: m.super_resolve_two_step(x))
+t_eager = timeit(lambda: m.super_resolve(x, use_graph=False))
+t_graph = timeit(lambda: m.super_resolve(x, use_graph=True))
+line = 'ESPCN 3x, batch 32x17x17: 4 launches (standalone d2s) %.1f us | 3 launches, fused store, eager %.1f us | the same as a HIP graph %.1f us (%.1f HR-MP/s)' % (
+    t_two, t_eager, t_graph, hr_px / t_graph)
 xb = torch.rand((1, 256, 256, 3), device=dev) * 2 - 1
 t_img = timeit(lambda: m.super_resolve(xb), 100)
 line += ' | one 256x256 image: %.1f us (%.1f HR-MP/s)' % (t_img, 768 * 768 / t_img)
+xl = torch.rand((256, 41, 41, 3), device=dev) * 2 - 1
+t_big2 = timeit(lambda: m.super_resolve_two_step(xl), 50)
+t_big = timeit(lambda: m.super_resolve(xl), 50)
+line += ' | 256x41x41: two-step %.1f us, fused %.1f us' % (t_big2, t_big)
 print(line)
