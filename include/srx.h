@@ -54,10 +54,15 @@ typedef enum { SRX_OP_FWD = 0, SRX_OP_BWD_DATA = 1, SRX_OP_BWD_FILTER = 2 } srx_
  * (K-1)/2; VALID -> OH = H-KH+1). */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, KW;
-    int32_t stride;        /* must be 1 (ENet's stride-2 discriminator is out of scope) */
+    int32_t stride;        /* must be 1.  (A stride-2 SAME 3x3 layer on an even-sized image -- ENet's discriminator,
+                            * enet/enet/model_enet.py:136-146 -- is the stride-1 layer sampled at the odd positions:
+                            * srx_subsample2 / srx_subsample2_bwd below.) */
     int32_t pad_mode;      /* srx_pad_mode */
     int32_t act;           /* srx_act fused after bias */
-    int32_t post_add_relu; /* relu after the skip add: enet/enet/model_enet.py:8-31 */
+    int32_t post_add_relu; /* activation applied AFTER the skip add: 0 none, SRX_ACT_RELU (1) relu(conv + skip) as in
+                            * enet/enet/model_enet.py:8-31, SRX_ACT_LRELU (3) leaky ReLU -- the closing launch of a
+                            * layer whose input channels are accumulated over several launches (see
+                            * srx_conv2d_bwd_data_acc) */
     int32_t precision;     /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32); the only mode */
     int32_t subpixel_r;    /* srx_conv2d_fwd only.  0 / 1: y is [N,OH,OW,Cout].  r > 1: the epilogue stores through the
                             * sub-pixel (depth-to-space) index map, y is [N,OH*r,OW*r,Cout/(r*r)]:
@@ -108,6 +113,17 @@ int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const
 int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* w,
                         const float* x_in, int in_act, float* dx_out, void* ws, size_t ws_bytes,
                         srx_stream_t stream);
+
+/* The same without the activation mask but with an ACCUMULATE operand: dx_out = dx + dx_acc (dx_out may alias
+ * dx_acc).  Layers wider than the kernels' 64 channels (ENet's discriminator, VGG-19: enet/enet/model_enet.py:
+ * 118-162, enet/enet/model_vgg.py:65-99) keep their tensors as blocks of 64 channels; the data gradient of an
+ * input block is the sum over the output blocks of one launch each:
+ *   dx[ib] = sum_ob bwd_data(dpre[ob], w[ib][ob]);   then srx_act_bwd applies the activation mask once.
+ * The forward counterpart needs no extra entry point: y[ob] = act(sum_ib conv(x[ib], w[ib][ob]) + bias) is
+ * srx_conv2d_fwd with skip = the running sum, act = NONE and, in the last launch, post_add_relu = the layer's
+ * activation.  The filter gradients of the block pairs are independent srx_conv2d_bwd_filter calls. */
+int srx_conv2d_bwd_data_acc(const srx_conv_desc* d, const float* dpre, const float* w, const float* dx_acc,
+                            float* dx_out, void* ws, size_t ws_bytes, srx_stream_t stream);
 
 /* Conv2DBackpropFilter + BiasAddGrad (+ the L2 regulariser's gradient):
  *   dw[kh,kw,ci,co] = sum_{n,oh,ow} x[n,oh+kh-pt,ow+kw-pl,ci] * dpre[n,oh,ow,co]
@@ -244,6 +260,81 @@ int srx_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W,
  * out = (y > 0) ? a + b : 0, y = the block input as saved (post-ReLU).  out may alias a or b. */
 int srx_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t numel,
                       srx_stream_t stream);
+
+/* ---- row A14 / "next" row N4: EnhanceNet-PAT's loss side (discriminator, VGG-19 features, perceptual / texture /
+ * adversarial losses: enet/enet/model_enet.py:118-261, enet/enet/model_vgg.py:11-99) -------------------------------- */
+
+/* tf.nn.max_pool(ksize 2x2, strides 2x2, padding='SAME') (enet/enet/model_vgg.py:28-36): [N,H,W,C] ->
+ * [N,ceil(H/2),ceil(W/2),C], C % 4 == 0.  _bwd = MaxPoolGrad given the forward INPUT x: the gradient of a window goes
+ * to its first maximum in scan order. */
+int srx_maxpool2x2(const float* in, float* out, int N, int H, int W, int C, srx_stream_t stream);
+int srx_maxpool2x2_bwd(const float* x, const float* dout, float* din, int N, int H, int W, int C,
+                       srx_stream_t stream);
+
+/* out[n,i,j,:] = in[n,2i+oy,2j+ox,:] ([N,H,W,C] -> [N,H/2,W/2,C]; H, W even, C % 4 == 0), and its gradient (zero
+ * stuffing): din[n,h,w,:] = (h%2==oy && w%2==ox) ? dout[n,h/2,w/2,:] : 0.
+ * tf.layers.conv2d(kernel_size=3, strides=2, padding='same') on an even-sized image pads 0 before / 1 after
+ * (enet/enet/model_enet.py:136-146), i.e. it IS the stride-1 SAME convolution sampled at (oy, ox) = (1, 1); its
+ * gradients are the stride-1 gradients of the zero-stuffed upstream gradient. */
+int srx_subsample2(const float* in, float* out, int N, int H, int W, int C, int oy, int ox, srx_stream_t stream);
+int srx_subsample2_bwd(const float* dout, float* din, int N, int H, int W, int C, int oy, int ox,
+                       srx_stream_t stream);
+
+/* Channel-blocked [blocks][pixels][64] <-> NHWC [pixels][blocks*64] (see srx_conv2d_bwd_data_acc). */
+int srx_channel_blocks_to_nhwc(const float* blocked, float* plain, size_t pixels, int blocks, srx_stream_t stream);
+int srx_nhwc_to_channel_blocks(const float* plain, float* blocked, size_t pixels, int blocks, srx_stream_t stream);
+
+/* normalize() of enet/enet/model_enet.py:34-41: y = x / (mean over channels + eps) per pixel, x [pixels, C]; and its
+ * gradient dx = dy / m - sum_c(dy x) / (C m^2), m = mean + eps. */
+int srx_channel_normalize(const float* x, float* y, size_t pixels, int C, float eps, srx_stream_t stream);
+int srx_channel_normalize_bwd(const float* x, const float* dy, float* dx, size_t pixels, int C, float eps,
+                              srx_stream_t stream);
+
+/* tf.extract_image_patches(ksizes 16x16, strides 16x16, 'VALID') + reshape to [N, (H/16)*(W/16), 256, C]
+ * (enet/enet/model_enet.py:237-250): x [N,H,W,C] -> patches; inverse != 0: patches (first argument) -> image
+ * (second argument), which is also the gradient of the forward map.  H, W multiples of 16, C of 4. */
+int srx_extract_patches16(const float* x, float* patches, int N, int H, int W, int C, int inverse,
+                          srx_stream_t stream);
+
+/* tf.losses.log_loss(labels = label everywhere, predictions = p, epsilon = eps, reduction=MEAN)
+ * (enet/enet/model_enet.py:165-182):
+ *   *loss_out (+)= loss_scale * mean_i( -label log(p_i + eps) - (1 - label) log(1 - p_i + eps) )
+ *   dp_i = grad_scale / n * ( -label / (p_i + eps) + (1 - label) / (1 - p_i + eps) )       (dp nullable) */
+int srx_log_loss(const float* p, float label, int n, float eps, float loss_scale, float grad_scale,
+                 float* loss_out, int accumulate, float* dp, srx_stream_t stream);
+
+/* VGG-19's input map (enet/enet/model_enet.py:288-289, enet/enet/model_vgg.py:72-76), [pixels, 3]:
+ *   out[..., c] = (in[..., 2-c] * 127.5 + 127.5) - (103.939, 116.779, 123.68)[c]
+ * backward != 0: the gradient map din[..., c] = 127.5 * dout[..., 2-c] (in = dout, out = din). */
+int srx_vgg_preprocess(const float* in, float* out, size_t pixels, int backward, srx_stream_t stream);
+
+/* out = alpha * a + beta * b (b nullable: out = alpha * a); out may alias a or b.  Sums of gradients that reach one
+ * tensor from two consumers (sr_images feeds VGG-19 and the discriminator: enet/enet/model_enet.py:291-298) and the
+ * loss weights of :204,:314-317. */
+int srx_add_scaled(const float* a, const float* b, float* out, size_t n, float alpha, float beta,
+                   srx_stream_t stream);
+
+/* out[j] = sum_i a[i*ld + j]: bias gradient of tf.layers.dense (enet/enet/model_enet.py:148-160). */
+int srx_column_sums(const float* a, float* out, int rows, int cols, int ld, srx_stream_t stream);
+
+/* Exact-fp32 batched GEMM with general strides (v_mfma_f32_16x16x4_f32):
+ *   C_b(m,n) = act( alpha * sum_k A_b(m,k) B_b(k,n) + bias(n) ) [+ C_b(m,n)]
+ *   X_b(i,j) = X[b * x_batch_stride + i * x_row_stride + j * x_col_stride]        (strides in elements)
+ * tf.layers.dense forward / backward (enet/enet/model_enet.py:148-160) and the gram matrices tf.matmul(x, x,
+ * transpose_a=True) over 16x16 patches and their gradient (:252-255).  bias nullable.  ws: optional workspace of
+ * srx_gemm_workspace_bytes() for a deterministic split of K when M*N is small (dense layers with M = batch). */
+typedef struct {
+    int32_t M, N, K, batch;
+    int64_t a_row_stride, a_col_stride, a_batch_stride;
+    int64_t b_row_stride, b_col_stride, b_batch_stride;
+    int64_t c_row_stride, c_col_stride, c_batch_stride;
+    float alpha;
+    int32_t act;        /* srx_act */
+    int32_t accumulate; /* != 0: add to C */
+} srx_gemm_desc;
+size_t srx_gemm_workspace_bytes(int M, int N, int K, int batch);
+int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* ws,
+             size_t ws_bytes, srx_stream_t stream);
 
 #ifdef __cplusplus
 }

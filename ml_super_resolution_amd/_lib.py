@@ -25,6 +25,9 @@ EXPORTS = [
     'srx_space_to_depth', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
     'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
     'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
+    'srx_conv2d_bwd_data_acc', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_subsample2', 'srx_subsample2_bwd',
+    'srx_channel_blocks_to_nhwc', 'srx_nhwc_to_channel_blocks', 'srx_channel_normalize', 'srx_channel_normalize_bwd',
+    'srx_extract_patches16', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
 ]
 
 
@@ -36,6 +39,14 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad_mode', 'act',
                  'post_add_relu', 'precision', 'subpixel_r')]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ('M', 'N', 'K', 'batch')] +
+                [(n, ctypes.c_int64) for n in ('a_row_stride', 'a_col_stride', 'a_batch_stride', 'b_row_stride',
+                                               'b_col_stride', 'b_batch_stride', 'c_row_stride', 'c_col_stride',
+                                               'c_batch_stride')] +
+                [('alpha', ctypes.c_float), ('act', ctypes.c_int32), ('accumulate', ctypes.c_int32)])
 
 
 _lib = None
@@ -88,6 +99,23 @@ def lib():
     L.srx_upsample_nearest.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srx_upsample_nearest_bwd.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srx_add_relu_grad.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.srx_conv2d_bwd_data_acc.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
+    L.srx_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
+    L.srx_maxpool2x2_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.srx_subsample2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    L.srx_subsample2_bwd.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    L.srx_channel_blocks_to_nhwc.argtypes = [vp, vp, sz, i, vp]
+    L.srx_nhwc_to_channel_blocks.argtypes = [vp, vp, sz, i, vp]
+    L.srx_channel_normalize.argtypes = [vp, vp, sz, i, f, vp]
+    L.srx_channel_normalize_bwd.argtypes = [vp, vp, vp, sz, i, f, vp]
+    L.srx_extract_patches16.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srx_log_loss.argtypes = [vp, f, i, f, f, f, vp, i, vp, vp]
+    L.srx_vgg_preprocess.argtypes = [vp, vp, sz, i, vp]
+    L.srx_column_sums.argtypes = [vp, vp, i, i, i, vp]
+    L.srx_add_scaled.argtypes = [vp, vp, vp, sz, f, f, vp]
+    L.srx_gemm_workspace_bytes.argtypes = [i, i, i, i]
+    L.srx_gemm_workspace_bytes.restype = sz
+    L.srx_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp, vp, vp, vp, vp, sz, vp]
     for name in EXPORTS:
         getattr(L, name)          # AttributeError if the library is stale
     _lib = L

@@ -263,7 +263,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4
             f32x4 v = act_apply4(acc[i], a.act, slope);
             if (AUX) {
                 if (a.skip) v += aux[i];
-                if (a.post_relu) v = act_apply4(v, ACT_RELU, 0.0f);
+                if (a.post_relu) v = act_apply4(v, a.post_relu, act_slope(a.post_relu));   // ReLU or leaky ReLU after the add
                 if (a.mask) v = act_grad4(v, aux[i], a.mask_act, mslope);
             }
 #ifdef SRX_TRACE
@@ -296,7 +296,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[G], const f32x4
                 if (cb + e < a.Cout) {
                     float t = v[e];
                     if (sk) t += sk[off[i] + e];
-                    if (AUX && a.post_relu) t = fmaxf(t, 0.f);
+                    if (AUX && a.post_relu) t = act_apply(t, a.post_relu);
                     if (mk) t *= act_grad_from_y(mk[off[i] + e], a.mask_act);
                     yb[off[i] + eo[e]] = t;
                 }

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long
             r = act_apply(r + ((c4 == 0) ? bias[0] : (c4 == 1 ? bias[1 < CO ? 1 : 0] : bias[2 < CO ? 2 : 0])), a.act);
             const size_t o = (size_t)p * CO + c4;
             if (a.skip) r += a.skip[o];
-            if (a.post_relu) r = fmaxf(r, 0.0f);
+            if (a.post_relu) r = act_apply(r, a.post_relu);
             a.y[o] = r;
         }
     }

@@ -76,6 +76,18 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace
+namespace srx {
+// the same for the other translation units with extern "C" entry points (enet_ops.hip)
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace srx
+namespace {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -190,6 +202,8 @@ int check_desc(const srx_conv_desc* d) {
     if (d->stride != 1) return fail(SRX_ERR_UNSUPPORTED, "stride %d: only stride 1 is implemented", d->stride);
     if (d->pad_mode != SRX_PAD_SAME && d->pad_mode != SRX_PAD_VALID) return fail(SRX_ERR_BAD_ARG, "bad pad_mode");
     if (d->act < SRX_ACT_NONE || d->act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad activation");
+    if (d->post_add_relu != 0 && d->post_add_relu != SRX_ACT_RELU && d->post_add_relu != SRX_ACT_LRELU)
+        return fail(SRX_ERR_BAD_ARG, "post_add_relu must be 0, SRX_ACT_RELU (1) or SRX_ACT_LRELU (3)");
     if (d->precision != 0) return fail(SRX_ERR_UNSUPPORTED, "precision mode %d not implemented", d->precision);
     if (d->subpixel_r < 0 || d->subpixel_r > 16) return fail(SRX_ERR_BAD_ARG, "bad subpixel_r %d", d->subpixel_r);
     if (d->subpixel_r > 1 && d->Cout % (d->subpixel_r * d->subpixel_r))
@@ -240,7 +254,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // vectors and images below 2^31 bytes.  Every other shape stays on the two-workgroup kernels.
     const int ppp = 256 / (p.cinp / 4), npart = 4 / p.nch;
     // Epilogue forms it implements (integer-VALU only): none / ReLU, ReLU-gradient mask, residual add (+ ReLU).
-    const bool epi_ok = (a.act == ACT_NONE || a.act == ACT_RELU) && !(a.mask && a.skip) && !(wt && a.skip) && !(!wt && a.mask) &&
+    const bool epi_ok = (a.act == ACT_NONE || a.act == ACT_RELU) && (a.post_relu == 0 || a.post_relu == ACT_RELU) && !(a.mask && a.skip) && !(wt && a.skip) && !(!wt && a.mask) &&
                         (!a.mask || (a.mask_act == ACT_RELU && a.act == ACT_NONE && !a.post_relu));
     // (p.RS == W + pad_l: the only pad slots of a tile row are the pad_l leading ones, which the scalar staging
     // never writes; a dgrad of a VALID layer has trailing pad slots inside the row as well and stays on path 0)
@@ -372,12 +386,26 @@ int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const
     return dispatch_conv(p, false, a, (hipStream_t)stream, ws, ws_bytes);
 }
 
+static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float* w, const float* x_in, int in_act,
+                         const float* dx_acc, float* dx_out, void* ws, size_t ws_bytes, srx_stream_t stream);
+
 int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* w, const float* x_in, int in_act,
                         float* dx_out, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    return bwd_data_impl(d, dpre, w, x_in, in_act, nullptr, dx_out, ws, ws_bytes, stream);
+}
+
+int srx_conv2d_bwd_data_acc(const srx_conv_desc* d, const float* dpre, const float* w, const float* dx_acc, float* dx_out,
+                            void* ws, size_t ws_bytes, srx_stream_t stream) {
+    if (!dx_acc) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    return bwd_data_impl(d, dpre, w, nullptr, SRX_ACT_NONE, dx_acc, dx_out, ws, ws_bytes, stream);
+}
+
+static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float* w, const float* x_in, int in_act,
+                         const float* dx_acc, float* dx_out, void* ws, size_t ws_bytes, srx_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dpre || !w || !dx_out) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
-    if (!aligned16(dpre) || !aligned16(w) || !aligned16(dx_out) || (x_in && !aligned16(x_in)))
+    if (!aligned16(dpre) || !aligned16(w) || !aligned16(dx_out) || (x_in && !aligned16(x_in)) || (dx_acc && !aligned16(dx_acc)))
         return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     if (in_act < SRX_ACT_NONE || in_act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad in_act");
     int pt, pl, OH, OW;
@@ -388,7 +416,7 @@ int srx_conv2d_bwd_data(const srx_conv_desc* d, const float* dpre, const float* 
     if (rc) return rc;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dpre; a.w = w; a.bias = nullptr; a.skip = nullptr; a.mask = x_in; a.y = dx_out;
+    a.x = dpre; a.w = w; a.bias = nullptr; a.skip = dx_acc; a.mask = x_in; a.y = dx_out;
     fill_conv_args(&a, p, d->N, OH, OW, d->Cout, d->Cin);
     a.act = SRX_ACT_NONE; a.post_relu = 0; a.mask_act = in_act;
     return dispatch_conv(p, true, a, (hipStream_t)stream, ws, ws_bytes);

@@ -15,7 +15,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (j < n) {
         const float* p = part + j;
-        for (int g = pg; g < G; g += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)g * stride);
+        // all of a thread's loads in flight at once (the launch is two waves of blocks: its time is memory round
+        // trips, not bytes); the order of the additions stays g = pg, pg+16, ...: results are unchanged
+        int g = pg;
+        for (; g + 7 * 16 < G; g += 8 * 16) {
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(g + 16 * i) * stride);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; g < G; g += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)g * stride);
     }
     sh[pg][c] = s;
     __syncthreads();

@@ -110,3 +110,16 @@ def shard(batch, rank, world_size):
         raise ValueError('global batch %d not divisible by world size %d' % (n, world_size))
     per = n // world_size
     return batch[rank * per:(rank + 1) * per]
+
+
+def attach_flat(model, world_size):
+    """EnhanceNet (BASELINE config 5): two parameter groups, `g_` and `d_` (enet/enet/model_enet.py:331-343), each
+    one flat buffer -> one all-reduce(AVG) per trainer run.  Replicas start from rank 0's weights."""
+    bufs = [model.generator.params]
+    if getattr(model, 'discriminator', None) is not None:
+        bufs.append(model.discriminator.pool.params)
+    for b in bufs:
+        broadcast_(b, 0)
+    model.grad_hook_g = lambda g: allreduce_mean_(g, world_size)
+    model.grad_hook_d = lambda g: allreduce_mean_(g, world_size)
+    return model

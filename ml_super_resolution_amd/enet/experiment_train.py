@@ -1,0 +1,105 @@
+"""
+experiment_train.py -- mirror of enet/enet/experiment_train.py: flags `train_dir_path, vgg19_path, ckpt_path,
+log_path, model='pat', batch_size=64` (:164-170) and the alternating schedule of its main loop (:105-160):
+
+  step = session.run(model['step'])
+  every 3rd step (step % 3 == 0) and if the model has a discriminator: ONE d_trainer run on a batch of its own,
+  then always ONE g_trainer run on the next batch (which increments the global step).
+
+Batches are (sd 32x32, bq 128x128, hd 128x128) in [-1, 1] (experiment_train.py:15-22); the reference decodes a
+directory of images on the host (enet/enet/datasets.py); here `--train_dir_path` may be an .npz of {'sd','bq','hd'}
+or absent (synthetic batches).  VGG-19 weights: the .npz the reference downloads (`--vgg19_path`); when it is absent
+and `--allow_random_vgg true`, VGG-shaped random weights (timing / smoke runs only).
+With WORLD_SIZE > 1 (torchrun) the batch is sharded and the gradients of BOTH trainers are all-reduced (one flat
+buffer each), as SURVEY 8e prescribes for config 5.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+from .. import dist as srx_dist
+from . import model_enet, model_vgg
+
+
+def parse_flags(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--train_dir_path', default=None)
+    ap.add_argument('--vgg19_path', default=None)
+    ap.add_argument('--ckpt_path', default=None)
+    ap.add_argument('--log_path', default=None)
+    ap.add_argument('--model', default='pat')
+    ap.add_argument('--batch_size', type=int, default=64)
+    # not in the reference (its loop never ends): stop after this many generator steps
+    ap.add_argument('--stop_training_at_k_step', type=int, default=None)
+    ap.add_argument('--allow_random_vgg', default='false')
+    return ap.parse_args(argv)
+
+
+def synthetic_batches(batch_size, device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    while True:
+        hd = torch.rand((batch_size, 128, 128, 3), device=device, generator=g) * 2 - 1
+        sd = hd.view(batch_size, 32, 4, 32, 4, 3).mean(dim=(2, 4))
+        bq = sd.repeat_interleave(4, dim=1).repeat_interleave(4, dim=2)
+        yield sd.contiguous(), bq.contiguous(), hd
+
+
+def npz_batches(path, batch_size, device, seed=0):
+    z = np.load(path)
+    sd, bq, hd = (z[k].astype(np.float32) for k in ('sd', 'bq', 'hd'))
+    rng = np.random.default_rng(seed)
+    while True:
+        idx = rng.integers(0, sd.shape[0], size=batch_size)
+        yield tuple(torch.from_numpy(a[idx]).to(device) for a in (sd, bq, hd))
+
+
+def main(argv=None, log=None):
+    """`log`: optional callable receiving one dict per trainer run (tests)."""
+    FLAGS = parse_flags(argv)
+    if FLAGS.model not in ('p', 'pa', 'pat'):
+        FLAGS.model = 'pat'                                              # experiment_train.py:88-89
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    device = torch.device('cuda', torch.cuda.current_device())
+    if world > 1:
+        srx_dist.init_process_group(rank, world, local_rank)
+    if FLAGS.batch_size % world:
+        raise SystemExit('batch_size must be divisible by the number of GPUs')
+    weights = model_vgg.load_vgg_weights(FLAGS.vgg19_path) if FLAGS.vgg19_path else {}
+    if not weights:
+        if str(FLAGS.allow_random_vgg).lower() not in ('1', 'true', 'yes'):
+            raise SystemExit('VGG-19 weights not found at %r (pass --allow_random_vgg true for a smoke run)' % (FLAGS.vgg19_path,))
+        weights = model_vgg.random_vgg_weights(0)
+    m = model_enet.EnetModel(FLAGS.model, weights, device=device)
+    if world > 1:
+        srx_dist.attach_flat(m, world)
+    per_rank = FLAGS.batch_size // world
+    batches = (npz_batches(FLAGS.train_dir_path, per_rank, device, seed=rank) if FLAGS.train_dir_path
+               else synthetic_batches(per_rank, device, seed=rank))
+    while True:
+        step = m.global_step
+        if FLAGS.stop_training_at_k_step is not None and step >= FLAGS.stop_training_at_k_step:
+            break
+        # NOTE: train discriminator (experiment_train.py:111-131)
+        if step % 3 == 0 and m.discriminator is not None:
+            a_loss = m.d_step(*next(batches))
+            if log is not None:
+                log({'step': step, 'trainer': 'd', 'a_loss': a_loss.item()})
+        # NOTE: train generator (:133-160)
+        losses = m.g_step(*next(batches))
+        if log is not None:
+            log(dict({'step': step, 'trainer': 'g'}, **{k: v.item() for k, v in losses.items() if k != 'a_loss'}))
+        if rank == 0 and (step + 1) % 100 == 0:
+            print(json.dumps({'step': step + 1, 'g_loss_all': losses['g_loss_all'].item()}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return m
+
+
+if __name__ == '__main__':
+    main()

@@ -1,23 +1,34 @@
 """
-model_enet.py -- the EnhanceNet GENERATOR of enet/enet/model_enet.py (reference) on the MI355X
-engine: forward, and the backward + Adam update of the generator variables for a given gradient on
-sr_images (the discriminator and the VGG-19 perceptual / texture losses that
-produce that gradient in the reference are rows A14 / N4 and not built).
+model_enet.py -- mirror of enet/enet/model_enet.py (reference) on the MI355X engine: the EnhanceNet generator, the
+discriminator, the perceptual / texture / adversarial losses on VGG-19 features and the two trainers of `build_enet`.
 
-  3x3 conv 3->64 ReLU                                   (model_enet.py:63-70)
+Generator (model_enet.py:44-115), variables under `g_`:
+  3x3 conv 3->64 ReLU                                   (:63-70)
   10 x residual_block: 3x3 ReLU -> 1x1 -> relu(x + .)   (:8-31, :74-75)
   2 x [nearest-neighbour upsample x2 -> 3x3 conv ReLU]  (:78-89)
   3x3 conv ReLU, 3x3 conv -> 3, + bq_images             (:92-113)
 
-`build_enet(sd_images, bq_images, hd_images=None, ...)` keeps the reference's inference keys
-{'sd_images', 'bq_images', 'sr_images'} (:264-350 with hd_images None).  Variables live under the
-`g_` scope with tf.layers' default names (g_/conv2d, g_/conv2d_1, ...), as `build_enet` selects
-generator parameters by that prefix (:331-332).
+Discriminator (:118-162, row A14), variables under `d_`: 5 x [3x3 s1, 3x3 s2] with 32..512 filters, leaky ReLU 0.2,
+flatten, dense 1024 leaky ReLU, dense 1 sigmoid.  `build_enet` calls build_discriminator twice (real, fake) inside
+`tf.variable_scope('d_', reuse=tf.AUTO_REUSE)`; the scope is closed in between, which resets TensorFlow's counters
+for the unnamed tf.layers scopes, so both calls resolve to d_/conv2d .. d_/conv2d_9, d_/dense, d_/dense_1: ONE set
+of weights (as the GAN needs).
+
+Losses (:165-261, row N4): log-loss GAN terms, perceptual MSE on normalised block2_pool / block5_pool (weights 0.2 /
+0.02), texture MSE between gram matrices of 16x16 patches of normalised block1/2/3_conv1 (3e-7 / 1e-6 / 1e-6).
+`build_enet` (:264-350): g_losses = p_loss [+ g_loss * (2 if 't' else 1)] [+ t_loss]; g_trainer = Adam(1e-4) on the
+`g_` variables (increments global_step), d_trainer = Adam(1e-4) on the `d_` variables minimising a_loss.
+
+`build_enet(sd_images, bq_images, hd_images, pat_model, vgg19_path)` keeps the reference's keys:
+  {sd_images, bq_images, sr_images} (+ hd_images, a_loss, g_loss, t_loss, p_loss, g_loss_all, g_trainer, d_trainer, step).
 """
+import numpy as np
 import torch
 
 from .. import graph, ops
+from ..blocked import BlockedConv, DenseLayer, ParamPool, to_blocks, to_nhwc
 from ..engine import truncated_normal_
+from . import model_vgg
 
 
 def generator_layers():
@@ -161,14 +172,301 @@ class EnetGenerator(object):
         return {k: vals[k].detach().cpu().numpy() for k in keys}
 
 
-def build_enet(sd_images, bq_images, hd_images=None, pat_model=True, vgg19_path=None, device='cuda', seed=None):
-    """Inference graph of enet/enet/model_enet.py:264-350 (hd_images must be None: training the
-    generator needs the discriminator / VGG-19 losses, which are out of scope)."""
-    if hd_images is not None:
-        raise NotImplementedError('EnhanceNet training (discriminator, VGG-19 perceptual / texture losses) is '
-                                  'outside the ported hot path; only the generator forward is provided')
-    g = EnetGenerator(device=device, seed=seed)
-    g.placeholders['sd_images'] = sd_images
-    g.placeholders['bq_images'] = bq_images
-    return {'sd_images': sd_images, 'bq_images': bq_images,
-            'sr_images': graph.Tensor('sr_images', owner=g, key='sr_images'), '_model': g}
+# ---------------------------------------------------------------------------------------------------------------------
+# discriminator (model_enet.py:118-162)
+# ---------------------------------------------------------------------------------------------------------------------
+def discriminator_layers(width=32):
+    """[(cin, cout, stride)] of the ten 3x3 convolutions: filters = 2 ** (i + 5) for i in 0..4 with width 32."""
+    layers, cin = [], 3
+    for i in range(5):
+        f = width * 2 ** i
+        layers += [(cin, f, 1), (f, f, 2)]
+        cin = f
+    return layers
+
+
+class Discriminator(object):
+    def __init__(self, device='cuda', seed=None, width=32, image_size=128, dense_units=1024):
+        """width / image_size / dense_units: the reference's 32 / 128 / 1024 (tests use smaller networks)."""
+        self.device = torch.device(device)
+        self.convs_spec = discriminator_layers(width)
+        self.features = (image_size // 32) ** 2 * self.convs_spec[-1][1]
+        shapes = []
+        for cin, cout, _ in self.convs_spec:
+            shapes += [BlockedConv.kernel_shape(cin, cout), (cout,)]
+        shapes += [(self.features, dense_units), (dense_units,), (dense_units, 1), (1,)]
+        self.pool = ParamPool(shapes, self.device)
+        P = self.pool
+        self.convs = [BlockedConv(cin, cout, stride, 'lrelu', P.view(2 * i), P.view(2 * i + 1), P.view(2 * i, P.grads), P.view(2 * i + 1, P.grads))
+                      for i, (cin, cout, stride) in enumerate(self.convs_spec)]
+        j = 2 * len(self.convs)
+        self.dense = [DenseLayer(self.features, dense_units, 'lrelu', P.view(j), P.view(j + 1), P.view(j, P.grads), P.view(j + 1, P.grads)),
+                      DenseLayer(dense_units, 1, 'sigmoid', P.view(j + 2), P.view(j + 3), P.view(j + 2, P.grads), P.view(j + 3, P.grads))]
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        for c in self.convs:                           # truncated_normal(stddev=0.02) (:122); biases zero
+            k = torch.empty((3, 3, c.cin, c.cout))
+            truncated_normal_(k, 0.02, gen)
+            c.set_kernel_hwio(k)
+        for d in self.dense:
+            truncated_normal_(d.w, 0.02, gen)
+        self._saved = None
+
+    def variables(self):
+        """{tf variable name: array-like in TensorFlow's layout} (kernels HWIO)."""
+        out = {}
+        for i, c in enumerate(self.convs):
+            scope = 'd_/conv2d' if i == 0 else 'd_/conv2d_%d' % i
+            out[scope + '/kernel'], out[scope + '/bias'] = c.kernel_hwio(), c.b
+        for i, d in enumerate(self.dense):
+            scope = 'd_/dense' if i == 0 else 'd_/dense_%d' % i
+            out[scope + '/kernel'], out[scope + '/bias'] = d.w, d.b
+        return out
+
+    def gradients(self):
+        out = {}
+        for i, c in enumerate(self.convs):
+            scope = 'd_/conv2d' if i == 0 else 'd_/conv2d_%d' % i
+            out[scope + '/kernel'], out[scope + '/bias'] = c.kernel_hwio(c.dw), c.db
+        for i, d in enumerate(self.dense):
+            scope = 'd_/dense' if i == 0 else 'd_/dense_%d' % i
+            out[scope + '/kernel'], out[scope + '/bias'] = d.dw, d.db
+        return out
+
+    def set_params(self, convs, dense):
+        """convs: 10 x (kernel HWIO, bias); dense: 2 x (W, b)."""
+        for c, (k, b) in zip(self.convs, convs):
+            c.set_kernel_hwio(k, b)
+        for d, (w, b) in zip(self.dense, dense):
+            d.w.copy_(torch.as_tensor(w, dtype=torch.float32).to(self.device))
+            d.b.copy_(torch.as_tensor(b, dtype=torch.float32).to(self.device))
+
+    def forward(self, images, keep=False):
+        """images [N,S,S,3] in [-1,1] -> probabilities [N,1]."""
+        t = to_blocks(images.contiguous())
+        acts = [t]
+        for c in self.convs:
+            t = c.forward(t)
+            acts.append(t)
+        flat = to_nhwc(t).contiguous().view(t.shape[1], -1)               # tf.layers.flatten of NHWC (:148)
+        if flat.shape[1] != self.features:
+            raise ValueError('discriminator built for %d features, got %d (its dense layer fixes the image size, '
+                             'model_enet.py:148-154)' % (self.features, flat.shape[1]))
+        h = self.dense[0].forward(flat)
+        p = self.dense[1].forward(h)
+        self._saved = (acts, flat, h, p) if keep else None
+        return p
+
+    def backward(self, dp, want_dx=True, want_dw=True):
+        """dp = d(loss)/d(p) [N,1] for the last forward(keep=True).  want_dw: fill the gradient buffer (d_trainer);
+        want_dx: return d(loss)/d(images) (the generator's adversarial gradient)."""
+        acts, flat, h, p = self._saved
+        dh = self.dense[1].backward(h, p, dp, want_dx=True, want_dw=want_dw)
+        dflat = self.dense[0].backward(flat, h, dh, want_dx=True, want_dw=want_dw)
+        last = acts[-1]
+        g = to_blocks(dflat.view(last.shape[1], last.shape[2], last.shape[3], -1))
+        for i in range(len(self.convs) - 1, -1, -1):
+            c, y = self.convs[i], acts[i + 1]
+            dpre = torch.empty_like(g)
+            for b in range(g.shape[0]):
+                ops.act_bwd(g[b], y[b], 'lrelu', out=dpre[b])
+            if want_dw:
+                c.wgrad(acts[i], dpre)
+            if i == 0 and not want_dx:
+                return None
+            g = c.dgrad(dpre)
+        return to_nhwc(g)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# losses on VGG-19 features (model_enet.py:185-261)
+# ---------------------------------------------------------------------------------------------------------------------
+PERCEPTUAL_LAYERS = (('block2_pool', 0.2), ('block5_pool', 0.02))                               # :186-206
+TEXTURE_LAYERS = (('block1_conv1', 3e-7), ('block2_conv1', 1e-6), ('block3_conv1', 1e-6))      # :214-218
+
+
+def perceptual_loss(sr_feats, hd_feats, loss_out, want_grad=True):
+    """loss_out = 0.2 * MSE(normalize(block2_pool)) + 0.02 * MSE(normalize(block5_pool)); returns
+    {layer: d loss / d sr feature (NHWC)}."""
+    dt = {}
+    for j, (name, wgt) in enumerate(PERCEPTUAL_LAYERS):
+        s, h = model_vgg.Vgg19.tap(sr_feats, name), model_vgg.Vgg19.tap(hd_feats, name)
+        sn, hn = ops.channel_normalize(s), ops.channel_normalize(h)
+        # loss (+)= wgt * mean((sn - hn)^2); dsn = wgt * 2 (sn - hn) / numel
+        dsn = ops.mse_fwd_bwd(sn, hn, loss_out, inv_numel=wgt / sn.numel(), accumulate=j > 0, want_grad=want_grad)
+        if want_grad:
+            dt[name] = ops.channel_normalize_bwd(s, dsn)
+    return dt
+
+
+def texture_matching_loss(sr_feats, hd_feats, loss_out, want_grad=True):
+    """loss_out = sum_l w_l * MSE(gram(sr_l), gram(hd_l)), gram = x^T x over each 16x16 patch of the normalised
+    features ([N, h*w/256, 256, C] -> [N, h*w/256, C, C]); returns {layer: d loss / d sr feature (NHWC)}."""
+    dt = {}
+    for j, (name, wgt) in enumerate(TEXTURE_LAYERS):
+        s, h = model_vgg.Vgg19.tap(sr_feats, name), model_vgg.Vgg19.tap(hd_feats, name)
+        n, hh, ww, c = s.shape
+        sp = ops.extract_patches16(ops.channel_normalize(s)).view(-1, 256, c)
+        hp = ops.extract_patches16(ops.channel_normalize(h)).view(-1, 256, c)
+        gs = ops.gemm(sp, sp, trans_a=True)                                 # [N*P, C, C]
+        gh = ops.gemm(hp, hp, trans_a=True)
+        dg = ops.mse_fwd_bwd(gs, gh, loss_out, inv_numel=wgt / gs.numel(), accumulate=j > 0, want_grad=want_grad)
+        if want_grad:
+            # d(x^T x) -> dx = x (dG + dG^T); dG is symmetric here (a difference of gram matrices): dx = 2 x dG
+            dsp = ops.gemm(sp, dg, alpha=2.0)
+            dsn = ops.extract_patches16_bwd(dsp.view(n, -1, 256, c), (n, hh, ww, c))
+            dt[name] = ops.channel_normalize_bwd(s, dsn)
+    return dt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# build_enet (model_enet.py:264-350)
+# ---------------------------------------------------------------------------------------------------------------------
+class EnetModel(object):
+    """Generator + VGG-19 + discriminator + the two Adam trainers.  The eager API works on device tensors:
+      g_step(sd, bq, hd) -> losses      one `session.run(g_trainer)` (step += 1)
+      d_step(sd, bq, hd) -> a_loss      one `session.run(d_trainer)`."""
+
+    def __init__(self, pat_model='pat', vgg_weights=None, device='cuda', seed=None, d_width=32, image_size=128, dense_units=1024):
+        self.device = torch.device(device)
+        self.pat_model = pat_model
+        self.generator = EnetGenerator(device=device, seed=seed)
+        self.vgg = model_vgg.Vgg19(vgg_weights, device=device)
+        self.discriminator = Discriminator(device=device, seed=None if seed is None else seed + 1, width=d_width,
+                                           image_size=image_size, dense_units=dense_units) if 'a' in pat_model else None
+        self.g_state = {}
+        self.global_step = 0
+        self.losses = {k: torch.zeros(1, dtype=torch.float32, device=self.device)
+                       for k in ('p_loss', 't_loss', 'g_loss', 'a_loss', 'g_loss_all')}
+        self.placeholders = {}
+        self.last_sr = None
+        self.grad_hook_g = self.grad_hook_d = None       # data parallelism: called with the flat gradient buffers
+
+    # ---- objective and its gradient w.r.t. sr_images ------------------------------------------------------------
+    def generator_objective(self, sr, hd, want_grad=True, want_a_loss=False):
+        """Fills self.losses (device scalars) and returns d(g_losses)/d(sr_images) (model_enet.py:286-326).
+        want_a_loss: also evaluate a_loss = log_loss(0, D(sr)) + log_loss(1, D(hd)) (:301; not part of g_losses)."""
+        L = self.losses
+        hd_f = self.vgg.forward(hd, keep=False)
+        sr_f = self.vgg.forward(sr, keep=want_grad)                        # (last: backward() uses what it saved)
+        dt = perceptual_loss(sr_f, hd_f, L['p_loss'], want_grad)
+        ops.add_scaled(L['p_loss'], out=L['g_loss_all'])
+        d_sr = None
+        if 'a' in self.pat_model:
+            D = self.discriminator
+            gw = 2.0 if 't' in self.pat_model else 1.0                     # :310-313
+            if want_a_loss:
+                ops.log_loss(D.forward(hd), 1.0, L['a_loss'], want_grad=False)
+            fake = D.forward(sr, keep=want_grad)
+            if want_a_loss:
+                ops.log_loss(fake, 0.0, L['a_loss'], accumulate=True, want_grad=False)
+            dp = ops.log_loss(fake, 1.0, L['g_loss'], grad_scale=gw, want_grad=want_grad)      # generator_loss (:165-169)
+            ops.add_scaled(L['g_loss_all'], L['g_loss'], 1.0, gw, out=L['g_loss_all'])
+            if want_grad:
+                d_sr = D.backward(dp, want_dx=True, want_dw=False).contiguous()
+        if 't' in self.pat_model:
+            dtt = texture_matching_loss(sr_f, hd_f, L['t_loss'], want_grad)
+            ops.add_scaled(L['g_loss_all'], L['t_loss'], out=L['g_loss_all'])
+            for k, v in dtt.items():
+                dt[k] = ops.add_scaled(dt[k], v, out=v) if k in dt else v
+        if not want_grad:
+            return None
+        d_vgg = self.vgg.backward(dt)
+        return d_vgg if d_sr is None else ops.add_scaled(d_vgg, d_sr, out=d_vgg)
+
+    # ---- trainers ---------------------------------------------------------------------------------------------------
+    def g_step(self, sd, bq, hd, lr=1e-4, want_a_loss=False):
+        sr = self.last_sr = self.generator.forward(sd, bq, keep=True)
+        d_sr = self.generator_objective(sr, hd, want_a_loss=want_a_loss)
+        grads = self.generator.backward(d_sr)
+        if self.grad_hook_g is not None:
+            self.grad_hook_g(self.generator.grads)
+        self.generator.adam_step(grads, self.g_state, lr)                 # AdamOptimizer(0.0001) on g_vars (:336-337)
+        self.global_step += 1
+        return self.losses
+
+    def d_step(self, sd, bq, hd, lr=1e-4):
+        """a_loss = log_loss(0, D(G(sd))) + log_loss(1, D(hd)); Adam(0.0001) on the d_ variables (:339-343).  One
+        discriminator pass over the concatenated batch [fake; real]: each half's mean has its own 1/N."""
+        D = self.discriminator
+        sr = self.generator.forward(sd, bq)
+        n = sr.shape[0]
+        both = torch.cat([sr, hd], dim=0)
+        p = D.forward(both, keep=True)
+        dp = torch.empty_like(p)
+        dp[:n] = ops.log_loss(p[:n].contiguous(), 0.0, self.losses['a_loss'])
+        dp[n:] = ops.log_loss(p[n:].contiguous(), 1.0, self.losses['a_loss'], accumulate=True)
+        D.backward(dp, want_dx=False, want_dw=True)
+        if self.grad_hook_d is not None:
+            self.grad_hook_d(D.pool.grads)
+        D.pool.adam_step(lr)
+        return self.losses['a_loss']
+
+    # ---- Session.run backend ---------------------------------------------------------------------------------------
+    def run(self, keys, feed_dict):
+        feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}
+        out = {}
+        need = [k for k in keys if k != 'step']
+        if need:
+            for k in ('sd_images', 'bq_images'):
+                if k not in feeds:
+                    raise ValueError('%s must be fed to fetch %s' % (k, ', '.join(need)))
+            sd = graph.to_device(feeds['sd_images'], self.device)
+            bq = graph.to_device(feeds['bq_images'], self.device)
+            hd = graph.to_device(feeds['hd_images'], self.device) if 'hd_images' in feeds else None
+            loss_keys = [k for k in need if k in self.losses]
+            if ('g_trainer' in keys or 'd_trainer' in keys or loss_keys) and hd is None:
+                raise ValueError('hd_images must be fed to fetch losses / trainers')
+            sr = None
+            want_a = 'a_loss' in keys and 'a' in self.pat_model
+            if 'd_trainer' in keys:
+                self.d_step(sd, bq, hd)                 # (leaves a_loss of its batch in self.losses)
+                want_a = False
+            if 'g_trainer' in keys:
+                self.g_step(sd, bq, hd, want_a_loss=want_a)
+                sr = self.last_sr
+            elif [k for k in loss_keys if k != 'a_loss' or want_a]:
+                sr = self.generator.forward(sd, bq)
+                self.generator_objective(sr, hd, want_grad=False, want_a_loss=want_a)
+            vals = {'sd_images': sd, 'bq_images': bq, 'hd_images': hd}
+            for k in need:
+                if k in ('g_trainer', 'd_trainer'):
+                    out[k] = None
+                elif k in self.losses:
+                    out[k] = float(self.losses[k].item())
+                elif k == 'sr_images':
+                    sr = sr if sr is not None else self.generator.forward(sd, bq)
+                    out[k] = sr.detach().cpu().numpy()
+                else:
+                    out[k] = vals[k].detach().cpu().numpy()
+        if 'step' in keys:
+            out['step'] = self.global_step
+        return out
+
+
+def build_enet(sd_images, bq_images, hd_images=None, pat_model='pat', vgg19_path=None, device='cuda', seed=None,
+               vgg_weights=None):
+    """enet/enet/model_enet.py:264-350.  hd_images None: the inference graph {sd_images, bq_images, sr_images}.
+    Otherwise the training graph; `vgg19_path` is the .npz of VGG-19 weights the reference loads (:283), or pass
+    `vgg_weights` ({layer: {layer_W_1, layer_b_1}}) directly."""
+    if hd_images is None:
+        g = EnetGenerator(device=device, seed=seed)
+        g.placeholders['sd_images'] = sd_images
+        g.placeholders['bq_images'] = bq_images
+        return {'sd_images': sd_images, 'bq_images': bq_images,
+                'sr_images': graph.Tensor('sr_images', owner=g, key='sr_images'), '_model': g}
+    if pat_model not in ('p', 'pa', 'pat'):
+        pat_model = 'pat'                                # experiment_train.py:88-89
+    if vgg_weights is None:
+        vgg_weights = model_vgg.load_vgg_weights(vgg19_path)
+        if not vgg_weights:
+            raise ValueError('VGG-19 weights not found at %r (the reference downloads them: model_vgg.py:4-5)' % (vgg19_path,))
+    m = EnetModel(pat_model, vgg_weights, device=device, seed=seed)
+    m.placeholders.update({'sd_images': sd_images, 'bq_images': bq_images, 'hd_images': hd_images})
+    T = lambda key: graph.Tensor(key, owner=m, key=key)
+    model = {'sd_images': sd_images, 'bq_images': bq_images, 'sr_images': T('sr_images'), 'hd_images': hd_images, '_model': m}
+    if 'a' in pat_model:
+        model.update({'a_loss': T('a_loss'), 'g_loss': T('g_loss'), 'd_trainer': T('d_trainer')})
+    if 't' in pat_model:
+        model['t_loss'] = T('t_loss')
+    model.update({'step': T('step'), 'p_loss': T('p_loss'), 'g_loss_all': T('g_loss_all'), 'g_trainer': T('g_trainer')})
+    return model

@@ -304,3 +304,185 @@ def add_relu_grad(a, b, y, out=None):
     out = out if out is not None else torch.empty_like(a)
     check(lib().srx_add_relu_grad(_ptr(a), _ptr(b), _ptr(y), _ptr(out), a.numel(), _stream()), 'srx_add_relu_grad')
     return out
+
+
+# ---- EnhanceNet-PAT's loss side ------------------------------------------------------------
+def conv2d_bwd_data_acc(dpre, w, x_shape, dx_acc, padding='same', out=None):
+    """dx_acc + Conv2DBackpropInput(dpre, w) -- srx_conv2d_bwd_data_acc (out may be dx_acc itself)."""
+    for t, n in ((dpre, 'dpre'), (w, 'w'), (dx_acc, 'dx_acc')):
+        _chk(t, n)
+    d = conv_desc(x_shape, w.shape, padding)
+    dx = out if out is not None else torch.empty(tuple(x_shape), dtype=torch.float32, device=dpre.device)
+    ws = sched_workspace(dpre.device)
+    check(lib().srx_conv2d_bwd_data_acc(ctypes.byref(d), _ptr(dpre), _ptr(w), _ptr(dx_acc), _ptr(dx),
+                                        ctypes.c_void_p(ws.data_ptr()), 256, _stream()), 'srx_conv2d_bwd_data_acc')
+    return dx
+
+
+def maxpool2x2(x, out=None):
+    """tf.nn.max_pool(ksize 2, strides 2, 'SAME'): [N,H,W,C] -> [N,ceil(H/2),ceil(W/2),C]."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = out if out is not None else torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_maxpool2x2(_ptr(x), _ptr(out), N, H, W, C, _stream()), 'srx_maxpool2x2')
+    return out
+
+
+def maxpool2x2_bwd(x, dout, out=None):
+    _chk(x, 'x'); _chk(dout, 'dout')
+    N, H, W, C = x.shape
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_maxpool2x2_bwd(_ptr(x), _ptr(dout), _ptr(out), N, H, W, C, _stream()), 'srx_maxpool2x2_bwd')
+    return out
+
+
+def subsample2(x, oy=1, ox=1, out=None):
+    """x[:, oy::2, ox::2, :] -- with (1, 1): a stride-1 SAME 3x3 convolution's output -> the stride-2 layer's."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = out if out is not None else torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_subsample2(_ptr(x), _ptr(out), N, H, W, C, oy, ox, _stream()), 'srx_subsample2')
+    return out
+
+
+def subsample2_bwd(dout, oy=1, ox=1, out=None):
+    """Zero stuffing: [N,h,w,C] -> [N,2h,2w,C] with dout at the (oy, ox) positions."""
+    _chk(dout, 'dout')
+    N, h, w, C = dout.shape
+    out = out if out is not None else torch.empty((N, 2 * h, 2 * w, C), dtype=torch.float32, device=dout.device)
+    check(lib().srx_subsample2_bwd(_ptr(dout), _ptr(out), N, 2 * h, 2 * w, C, oy, ox, _stream()), 'srx_subsample2_bwd')
+    return out
+
+
+def blocks_to_nhwc(blocked, out=None):
+    """[CB, N, H, W, 64] -> [N, H, W, CB*64]."""
+    _chk(blocked, 'blocked')
+    CB, N, H, W, cb = blocked.shape
+    if CB == 1:
+        return blocked[0]
+    if cb != 64:
+        raise ValueError('channel blocks must hold 64 channels')
+    out = out if out is not None else torch.empty((N, H, W, CB * 64), dtype=torch.float32, device=blocked.device)
+    check(lib().srx_channel_blocks_to_nhwc(_ptr(blocked), _ptr(out), N * H * W, CB, _stream()), 'srx_channel_blocks_to_nhwc')
+    return out
+
+
+def nhwc_to_blocks(plain, out=None):
+    """[N, H, W, C] -> [C/64, N, H, W, 64] (C <= 64: a view [1, N, H, W, C])."""
+    _chk(plain, 'plain')
+    N, H, W, C = plain.shape
+    if C <= 64:
+        return plain.view(1, N, H, W, C)
+    if C % 64:
+        raise ValueError('more than 64 channels must come in multiples of 64')
+    out = out if out is not None else torch.empty((C // 64, N, H, W, 64), dtype=torch.float32, device=plain.device)
+    check(lib().srx_nhwc_to_channel_blocks(_ptr(plain), _ptr(out), N * H * W, C // 64, _stream()), 'srx_nhwc_to_channel_blocks')
+    return out
+
+
+def channel_normalize(x, eps=1e-6, out=None):
+    """enet normalize(): x / (mean over the last axis + eps)."""
+    _chk(x, 'x')
+    C = x.shape[-1]
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_channel_normalize(_ptr(x), _ptr(out), x.numel() // C, C, float(eps), _stream()), 'srx_channel_normalize')
+    return out
+
+
+def channel_normalize_bwd(x, dy, eps=1e-6, out=None):
+    _chk(x, 'x'); _chk(dy, 'dy')
+    C = x.shape[-1]
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_channel_normalize_bwd(_ptr(x), _ptr(dy), _ptr(out), x.numel() // C, C, float(eps), _stream()),
+          'srx_channel_normalize_bwd')
+    return out
+
+
+def extract_patches16(x, out=None):
+    """[N,H,W,C] -> [N, (H/16)*(W/16), 256, C] (tf.extract_image_patches 16x16 / 16, reshaped)."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = out if out is not None else torch.empty((N, (H // 16) * (W // 16), 256, C), dtype=torch.float32, device=x.device)
+    check(lib().srx_extract_patches16(_ptr(x), _ptr(out), N, H, W, C, 0, _stream()), 'srx_extract_patches16')
+    return out
+
+
+def extract_patches16_bwd(dpatches, image_shape, out=None):
+    _chk(dpatches, 'dpatches')
+    N, H, W, C = image_shape
+    out = out if out is not None else torch.empty((N, H, W, C), dtype=torch.float32, device=dpatches.device)
+    check(lib().srx_extract_patches16(_ptr(dpatches), _ptr(out), N, H, W, C, 1, _stream()), 'srx_extract_patches16')
+    return out
+
+
+def log_loss(p, label, loss_out, loss_scale=1.0, grad_scale=1.0, accumulate=False, want_grad=True, eps=1e-7):
+    """loss_out (+)= loss_scale * tf.losses.log_loss(label, p); returns dp * grad_scale (or None)."""
+    _chk(p, 'p')
+    dp = torch.empty_like(p) if want_grad else None
+    check(lib().srx_log_loss(_ptr(p), float(label), p.numel(), float(eps), float(loss_scale), float(grad_scale),
+                             _ptr(loss_out), int(accumulate), _ptr(dp), _stream()), 'srx_log_loss')
+    return dp
+
+
+def vgg_preprocess(x, backward=False, out=None):
+    """[N,H,W,3] in [-1,1] RGB -> BGR 0..255 minus the ImageNet means; backward=True maps the gradient back."""
+    _chk(x, 'x')
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_vgg_preprocess(_ptr(x), _ptr(out), x.numel() // 3, int(backward), _stream()), 'srx_vgg_preprocess')
+    return out
+
+
+def add_scaled(a, b=None, alpha=1.0, beta=1.0, out=None):
+    """alpha * a + beta * b (b None: alpha * a); out may be a or b."""
+    _chk(a, 'a'); _chk(b, 'b')
+    if b is not None and a.shape != b.shape:
+        raise ValueError('add_scaled: shapes differ')
+    out = out if out is not None else torch.empty_like(a)
+    check(lib().srx_add_scaled(_ptr(a), _ptr(b), _ptr(out), a.numel(), float(alpha), float(beta), _stream()), 'srx_add_scaled')
+    return out
+
+
+def column_sums(a, out=None):
+    _chk(a, 'a')
+    rows, cols = a.shape
+    out = out if out is not None else torch.empty((cols,), dtype=torch.float32, device=a.device)
+    check(lib().srx_column_sums(_ptr(a), _ptr(out), rows, cols, cols, _stream()), 'srx_column_sums')
+    return out
+
+
+_gemm_ws = {}
+
+
+def gemm(A, B, bias=None, act=None, alpha=1.0, trans_a=False, trans_b=False, out=None, accumulate=False):
+    """C = act(alpha * op(A) @ op(B) + bias); A, B 2-D, or 3-D with a leading batch dimension (same batch count).
+    Exact fp32 on the MFMA unit -- srx_gemm."""
+    _chk(A, 'A'); _chk(B, 'B'); _chk(bias, 'bias')
+    batched = A.dim() == 3
+    if batched != (B.dim() == 3):
+        raise ValueError('A and B must both be batched or both be matrices')
+    a2, b2 = (A.shape[1:], B.shape[1:]) if batched else (A.shape, B.shape)
+    M, K = (a2[1], a2[0]) if trans_a else (a2[0], a2[1])
+    Kb, N = (b2[1], b2[0]) if trans_b else (b2[0], b2[1])
+    if K != Kb:
+        raise ValueError('inner dimensions differ: %d vs %d' % (K, Kb))
+    batch = A.shape[0] if batched else 1
+    shape = (batch, M, N) if batched else (M, N)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=A.device)
+    elif tuple(out.shape) != shape:
+        raise ValueError('out has shape %s, expected %s' % (tuple(out.shape), shape))
+    _chk(out, 'out')
+    d = _lib.GemmDesc(M, N, K, batch,
+                      1 if trans_a else a2[1], a2[1] if trans_a else 1, a2[0] * a2[1] if batched else 0,
+                      1 if trans_b else b2[1], b2[1] if trans_b else 1, b2[0] * b2[1] if batched else 0,
+                      N, 1, M * N if batched else 0, float(alpha), ACT_BY_NAME[act], int(accumulate))
+    need = lib().srx_gemm_workspace_bytes(M, N, K, batch)
+    ws = None
+    if need:
+        key = (A.device.index, torch.cuda.current_stream(A.device).cuda_stream)
+        ws = _gemm_ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _gemm_ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=A.device)
+    check(lib().srx_gemm(ctypes.byref(d), _ptr(A), _ptr(B), _ptr(bias), _ptr(out), _ptr(ws), ws.numel() * 4 if ws is not None else 0,
+                         _stream()), 'srx_gemm')
+    return out
