@@ -249,10 +249,14 @@ def texture_loss(sr_feats, hd_feats):
     return loss, dt
 
 
-def enet_losses_and_sr_gradient(sr, hd, vgg_weights, d_convs, d_dense, pat_model='pat'):
+def enet_losses_and_sr_gradient(sr, hd, vgg_weights, d_convs, d_dense, pat_model='pat', at_sr_feats=None, at_fake=None):
     """The generator's objective and its gradient with respect to sr_images (build_enet, model_enet.py:286-326):
-    g_losses = p_loss [+ g_loss * (2.0 if 't' in model else 1.0)] [+ t_loss].  Returns (dict of losses, d_sr)."""
-    sr_f = vgg19_forward(sr, vgg_weights)
+    g_losses = p_loss [+ g_loss * (2.0 if 't' in model else 1.0)] [+ t_loss].  Returns (dict of losses, d_sr).
+    at_sr_feats / at_fake: differentiate AT these activations (VGG-19 features of sr; (fake, saved) of the
+    discriminator) instead of the ones recomputed here.  The gradient is discontinuous where a ReLU input crosses zero
+    or two pooling candidates tie: a float32 forward pass lands on the other side of such a point now and then, and a
+    comparison must hold both gradients to the same side."""
+    sr_f = at_sr_feats if at_sr_feats is not None else vgg19_forward(sr, vgg_weights)
     hd_f = vgg19_forward(hd, vgg_weights)
     losses = {}
     p_loss, dt = perceptual_loss(sr_f, hd_f)
@@ -260,7 +264,7 @@ def enet_losses_and_sr_gradient(sr, hd, vgg_weights, d_convs, d_dense, pat_model
     total = p_loss
     d_sr = 0.0
     if 'a' in pat_model:
-        fake, saved = discriminator_forward(sr, d_convs, d_dense, keep=True)
+        fake, saved = at_fake if at_fake is not None else discriminator_forward(sr, d_convs, d_dense, keep=True)
         real = discriminator_forward(hd, d_convs, d_dense)
         lf, _ = log_loss(0.0, fake)
         lr_, _ = log_loss(1.0, real)
@@ -282,11 +286,12 @@ def enet_losses_and_sr_gradient(sr, hd, vgg_weights, d_convs, d_dense, pat_model
     return losses, d_sr
 
 
-def discriminator_loss_and_grads(sr, hd, d_convs, d_dense):
+def discriminator_loss_and_grads(sr, hd, d_convs, d_dense, at_fake=None, at_real=None):
     """a_loss = log_loss(0, D(sr)) + log_loss(1, D(hd)) and its gradient for the d_ variables (d_trainer,
-    model_enet.py:339-343; sr is the generator's output, a constant for this trainer's var_list)."""
-    fake, sf = discriminator_forward(sr, d_convs, d_dense, keep=True)
-    real, sr_ = discriminator_forward(hd, d_convs, d_dense, keep=True)
+    model_enet.py:339-343; sr is the generator's output, a constant for this trainer's var_list).
+    at_fake / at_real: (p, saved) to differentiate at (see enet_losses_and_sr_gradient)."""
+    fake, sf = at_fake if at_fake is not None else discriminator_forward(sr, d_convs, d_dense, keep=True)
+    real, sr_ = at_real if at_real is not None else discriminator_forward(hd, d_convs, d_dense, keep=True)
     lf, dpf = log_loss(0.0, fake)
     lr_, dpr = log_loss(1.0, real)
     _, cf, df = discriminator_backward(sf, fake, dpf, d_convs, d_dense, want_dx=False)
