@@ -1428,7 +1428,9 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
         acc[i] = bias4;
     }
     f32x4 aux[G];
-    conv_prefetch_aux<G, true>(aux, off, a, img_base, vec);
+    // (this kernel is always built with AUX: without a skip / mask operand there is nothing to fetch -- the
+    // unconditional prefetch would read through a null pointer)
+    conv_prefetch_aux<G, true>(aux, off, a, img_base, vec && (a.mask != nullptr || a.skip != nullptr));
     const int row_stride = a.RS * PS;
     const int co = cout0 + li;
     const bool co_ok = co < a.Cout;

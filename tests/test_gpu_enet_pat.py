@@ -372,3 +372,20 @@ def test_build_enet_keys_and_train_script_schedule():
     assert m.global_step == 5 and all(np.isfinite(r.get('g_loss_all', 0.0)) for r in log)
     with pytest.raises(SystemExit):
         experiment_train.main(['--model', 'pat', '--batch_size', '2', '--stop_training_at_k_step', '1'])
+
+
+@pytest.mark.parametrize('n,hw,cin,cout', [(2, 16, 8, 4), (2, 16, 4, 4), (2, 16, 3, 8), (2, 64, 3, 4)])
+def test_generic_kernel_without_aux_operand(n, hw, cin, cout):
+    """Regression (round 2): shapes outside the tuned instance set run conv_mfma_generic_kernel, which is always built
+    with the aux-operand epilogue; with 16-byte output vectors and NO skip / mask operand its prefetch read through a
+    null pointer (a GPU memory fault, found with a 4-channel discriminator).  Data gradients towards <= 4 staged
+    channels, and a 4x4 filter forward."""
+    from ml_super_resolution_amd import ops
+    rng = np.random.default_rng(cin * 10 + cout)
+    k = rng.normal(0, 0.3, (3, 3, cin, cout)).astype(np.float32)
+    dp = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    ref, _, _ = E.conv2d_same_bwd(np.zeros((n, hw, hw, cin)), k, dp, 1)
+    close(ops.conv2d_bwd_data(dev(dp), dev(k), (n, hw, hw, cin), 'same'), ref)
+    x = rng.normal(size=(n, 12, 12, 32)).astype(np.float32)
+    w = rng.normal(0, 0.1, (4, 4, 32, 8)).astype(np.float32)
+    close(ops.conv2d_fwd(dev(x), dev(w), None, 'valid', None), O.conv2d_fwd(x, w, None, 'VALID'))
