@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from oracle import oracle_enet as E
 
-torch.set_default_dtype(torch.float64)
+F64 = torch.float64       # (explicit everywhere: a process-wide default dtype would leak into the other test modules)
 
 
 def _t(a, grad=False):
@@ -29,7 +29,7 @@ def _conv_same(x, w, b, stride=1):
 
 def _vgg(x, weights):
     v = x * 127.5 + 127.5
-    t = torch.flip(v, dims=[-1]) - torch.tensor(E.VGG_MEAN_BGR)
+    t = torch.flip(v, dims=[-1]) - torch.tensor(E.VGG_MEAN_BGR, dtype=F64)
     feats = {}
     for name in E.VGG_LAYERS:
         if name.endswith('pool'):
