@@ -142,15 +142,17 @@ def cpu_library_baseline(rank):
         return {'value': None, 'error': repr(exc)}
 
 
+TRAFFIC_SOURCES = ('conv_kernels.hip.h', 'launchers.h', 'pipe_inst_k3c64.hip', 'srx_api.hip')
+
+
 def kernel_source_sha():
-    """sha256 over the HIP sources of libsrx.so: ties a number measured on an earlier build to the code it was
-    measured on."""
+    """sha256 over the sources that define the dominant kernel and its launch plan (the kernel header, its instance
+    file, the planner): ties a number measured on an earlier build to the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'ml_super_resolution_amd', 'csrc')
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.h')):
-            h.update(open(os.path.join(csrc, name), 'rb').read())
+    for name in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(csrc, name), 'rb').read())
     return h.hexdigest()[:16]
 
 
