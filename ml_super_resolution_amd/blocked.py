@@ -8,17 +8,25 @@ every block is an ordinary NHWC tensor for the C-ABI kernels.  A layer's kernel 
 [CIB, COB, 3, 3, ci, co] (each [ib][ob] slice a contiguous HWIO filter); `kernel_hwio()` / `set_kernel_hwio()`
 convert to and from TensorFlow's [3, 3, Cin, Cout] for checkpoints and tests.
 
-  forward   y[ob] = act( sum_ib conv(x[ib], w[ib][ob]) + bias[ob] ): one srx_conv2d_fwd per block pair, the running
-            sum passed as the `skip` operand (bias in the first launch, the activation -- after the add -- in the
-            last: post_add_relu = ReLU / leaky ReLU);
-  dgrad     dx[ib] = sum_ob bwd_data(dpre[ob], w[ib][ob]): srx_conv2d_bwd_data, then srx_conv2d_bwd_data_acc;
+  forward   y[ob] = act( sum_ib conv(x[ib], w[ib][ob]) + bias[ob] ): rows of <= 64 pixels: ONE launch for the layer
+            (srx_conv3x3_blocked: the sum over the input blocks stays in registers); wider images: one srx_conv2d_fwd
+            per block pair, the running sum passed as the `skip` operand (bias in the first launch, the activation
+            -- after the add -- in the last: post_add_relu = ReLU / leaky ReLU);
+  dgrad     dx[ib] = sum_ob bwd_data(dpre[ob], w[ib][ob]): srx_conv3x3_blocked with transposed filters, or
+            srx_conv2d_bwd_data followed by srx_conv2d_bwd_data_acc per further output block;
   wgrad     dw[ib][ob] = bwd_filter(x[ib], dpre[ob]), independent calls; dbias from the ib = 0 calls;
   stride 2  (TF pads 0 before / 1 after on an even image, model_enet.py:136-146) = the stride-1 layer sampled at the
             odd positions: srx_subsample2 after the forward, zero stuffing (srx_subsample2_bwd) before the gradients.
 """
+import os
+
 import torch
 
 from . import ops
+
+# layers wider than 64 channels on rows of <= 64 pixels: ONE launch per layer (srx_conv3x3_blocked) instead of one per
+# block pair; SRX_WIDE=0 keeps the block-pair launches (A/B)
+USE_WIDE = os.environ.get('SRX_WIDE', '1') != '0'
 
 
 def n_blocks(c):
@@ -103,6 +111,9 @@ class BlockedConv(object):
         cib, n, h, w, _ = x.shape
         assert cib == self.cib and x.shape[4] == self.ci
         y = torch.empty((self.cob, n, h, w, self.co), dtype=torch.float32, device=x.device)
+        if self._wide_ok(w):
+            ops.conv3x3_blocked(x, self.w, self.b, self.act, out=y)
+            return self._subsampled(y) if self.stride == 2 else y
         tmp = self._buf('fwd', y.shape, x.device) if self.cib > 1 else None
         # the launches of one output block alternate between two buffers (the column-strip kernels do not take an
         # in-place skip operand); an odd / even count decides where the first one must go so that the last lands in y
@@ -118,12 +129,18 @@ class BlockedConv(object):
                 ops.conv2d_fwd(x[ib], self.w[ib, ob], bias if ib == 0 else None, 'same', None,
                                skip=bufs[(ib + 1) % 2][ob] if ib > 0 else None,
                                post_add_relu=_POST_ACT[self.act] if last else 0, out=dst)
-        if self.stride == 2:
-            ys = torch.empty((self.cob, n, h // 2, w // 2, self.co), dtype=torch.float32, device=x.device)
-            for ob in range(self.cob):
-                ops.subsample2(y[ob], 1, 1, out=ys[ob])
-            return ys
-        return y
+        return self._subsampled(y) if self.stride == 2 else y
+
+    def _wide_ok(self, width):
+        return (USE_WIDE and (self.cib > 1 or self.cob > 1) and self.ci == 64 and self.co == 64 and width <= 64 and
+                self.act in (None, 'relu', 'lrelu', 'leaky_relu'))
+
+    def _subsampled(self, y):
+        cob, n, h, w, co = y.shape
+        ys = torch.empty((cob, n, h // 2, w // 2, co), dtype=torch.float32, device=y.device)
+        for ob in range(cob):
+            ops.subsample2(y[ob], 1, 1, out=ys[ob])
+        return ys
 
     # ---- backward -------------------------------------------------------------------------------------------------
     def _full_res(self, dpre):
@@ -141,6 +158,8 @@ class BlockedConv(object):
         dp = self._full_res(dpre)
         _, n, h, w, _ = dp.shape
         dx = torch.empty((self.cib, n, h, w, self.ci), dtype=torch.float32, device=dp.device)
+        if self._wide_ok(w):
+            return ops.conv3x3_blocked(dp, self.w, None, None, transpose=True, out=dx)
         xs = (n, h, w, self.ci)
         for ib in range(self.cib):
             ops.conv2d_bwd_data(dp[0], self.w[ib, 0], xs, 'same', out=dx[ib])

@@ -1,0 +1,194 @@
+// conv_wide.hip -- 3x3 SAME stride-1 convolution (forward / data gradient) of layers WIDER than 64 channels, on
+// channel-blocked tensors: x [SB][N,H,W,64] -> y [PB][N,H,W,64], filters [CIB][COB][3][3][64][64] (blocked.py).
+// VGG-19's blocks 2-5 and the discriminator's 128-512-channel layers (enet/enet/model_vgg.py:65-99,
+// enet/enet/model_enet.py:118-146).
+//
+// The 64-channel kernels serve such a layer one block pair per launch, the running sum going through HBM between
+// launches: 64 launches per 512 -> 512 layer, each a few microseconds of work at VGG's 8x8 / 16x16 maps.  Here ONE
+// launch covers the layer: a work unit is (a tile of <= 128 pixels of one image, one produced block of 64
+// channels); its accumulators (8 sub-tiles of 16 pixels x 16 channels per wave) stay in registers while the unit
+// walks the staged blocks -- per block: the wave's 3x3x64x16 filter slice (144 registers, from L2), the tile with
+// its halo through LDS (stage_tile), 9 x 16 k-steps of exact-fp32 MFMA per sub-tile (the software-pipelined
+// group body of conv_mfma_kernel).  Bound: fp32 MFMA; each filter slice is loaded once per 128 pixels.
+// dgrad = the same walk over the OUTPUT blocks with the filters read flipped + transposed (WT).
+#include <stdarg.h>
+
+#include "../../include/srx.h"
+#include "launchers.h"
+
+namespace srx {
+int set_error(int code, const char* fmt, ...);
+
+namespace {
+
+struct WideArgs {
+    const float* x;      // staged tensor, SB blocks of [N,H,W,64]
+    const float* w;      // blocked filters [CIB][COB][9][64][64] of the FORWARD layer
+    const float* bias;   // [PB*64] or null
+    float* y;            // produced tensor, PB blocks of [N,H,W,64]
+    int N, H, W, SB, PB;
+    int TH, RS, tiles_per_img, units_total;
+    float inv_rs;
+    int act;             // fused after the sum over the staged blocks: NONE / RELU / LRELU
+};
+
+constexpr int kPS = 68;          // LDS pixel stride in floats (64 + 4: conflict-free ds_read_b128 over 16 pixels)
+constexpr int kMaxSub = 8;       // sub-tiles of 16 pixels per unit (two groups of four accumulators)
+
+__device__ __forceinline__ void wide_group(f32x4 (&acc)[4], const int (&laddr)[4], const float (&wr)[144], const float* lds,
+                                           int row_stride) {
+    constexpr int NBLK = 36;     // 9 taps x 4 groups of 16 input channels
+    f32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i]);
+#pragma unroll
+    for (int t = 0; t < NBLK; ++t) {
+        if (t + 1 < NBLK) {
+            const int t1 = t + 1;
+            const int kh1 = (t1 / 4) / 3, kw1 = (t1 / 4) % 3, g1 = t1 % 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                nxt[i] = *reinterpret_cast<const f32x4*>(lds + laddr[i] + kh1 * row_stride + kw1 * kPS + 16 * g1);
+        }
+        const int wb = (t / 4) * 16 + 4 * (t % 4);
+        // GUARD: built with more than 256 registers (one workgroup per CU), so an operand may reach the block through
+        // a v_accvgpr_read -- a VALU write that needs wait states before an MFMA reads it
+        mfma_block<true>(acc, wr[wb], wr[wb + 1], wr[wb + 2], wr[wb + 3], cur);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+    }
+}
+
+template <bool WT>
+__global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int cout0 = wave * 16;
+    const size_t blk_elems = (size_t)a.N * a.H * a.W * 64;
+    const int row_stride = a.RS * kPS;
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    __builtin_amdgcn_s_setprio(2);
+    for (int u = u0; u < u1; ++u) {
+        // units of one tile are adjacent (the produced blocks re-read the same staged tiles: L2 serves them)
+        const int pb = u % a.PB;
+        const int tile = u / a.PB;
+        const int n = tile / a.tiles_per_img;
+        const int h0 = (tile % a.tiles_per_img) * a.TH;
+        const int th = (a.H - h0 < a.TH) ? (a.H - h0) : a.TH;
+        const int npx = th * a.W;
+        const int n_sub = (npx + 15) >> 4;
+        const int n_need = (th + 2) * a.RS + 2;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + pb * 64 + cout0 + 4 * kq);
+        f32x4 acc0[4], acc1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc0[i] = bias4; acc1[i] = bias4; }
+        const float inv_w = 1.0f / (float)a.W;
+        // lane's pixel of sub-tile i -> LDS address of its (tap 0,0) slot (sub-tiles past the tile compute on pixel 0 and
+        // are not stored).  Recomputed per group rather than kept: the kernel sits at the 256-register limit of two
+        // waves per SIMD (144 filter registers + 32 accumulators + 32 LDS fragments), and a dozen integer
+        // instructions per 576 MFMAs cost nothing.
+        auto group_addresses = [&](int first, int (&la)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (first + i) + li;
+                const int tt = (t < npx) ? t : 0;
+                const int orow = fdiv_small(tt, inv_w, a.W);
+                const int ocol = tt - orow * a.W;
+                la[i] = (orow * a.RS + ocol) * kPS + 4 * kq;
+            }
+        };
+        for (int sb = 0; sb < a.SB; ++sb) {
+            float wr[144];
+            ConvArgs wa;
+            const int wblock = WT ? (pb * a.SB + sb) : (sb * a.PB + pb);
+            wa.w = a.w + (size_t)wblock * (9 * 64 * 64);
+            wa.Cin = 64;
+            wa.Cout = 64;
+            // One workgroup per CU: 144 filter registers + 32 accumulators + the staging loads in flight do not fit the
+            // 256 registers of two waves per SIMD (tried: 28-138 spilled registers).  The filter loads are issued
+            // first and land while the tile is staged.
+            load_stationary_weights<9, 64, WT>(wr, wa, cout0, li, kq);
+            lds_barrier();                                                     // every wave is done with the previous tile
+            stage_tile<64>(lds, a.x + (size_t)sb * blk_elems, n, a.H, a.W, 64, h0 - 1, -1, a.RS, a.inv_rs, n_need, tid);
+            lds_barrier();
+            __builtin_amdgcn_s_setprio(0);
+            {
+                int la[4];
+                group_addresses(0, la);
+                wide_group(acc0, la, wr, lds, row_stride);
+            }
+            if (n_sub > 4) {
+                int la[4];
+                group_addresses(4, la);
+                wide_group(acc1, la, wr, lds, row_stride);
+            }
+            __builtin_amdgcn_s_setprio(2);
+        }
+        // MFMA results are read by VALU code next: software covers the result latency
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        float* yb = a.y + (size_t)pb * blk_elems + (size_t)n * a.H * a.W * 64 + (size_t)h0 * a.W * 64 + cout0 + 4 * kq;
+        const float slope = act_slope(a.act);
+        // pixel t of the tile is pixel t of the image rows h0.. (full-width tiles): its output offset is t * 64
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 16 * i + li;
+            if (t < npx) *reinterpret_cast<f32x4*>(yb + t * 64) = act_apply4(acc0[i], a.act, slope);
+        }
+        if (n_sub > 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (i + 4) + li;
+                if (t < npx) *reinterpret_cast<f32x4*>(yb + t * 64) = act_apply4(acc1[i], a.act, slope);
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace srx
+
+using namespace srx;
+
+extern "C" int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
+                                   int staged_blocks, int produced_blocks, int act, int transpose_filters,
+                                   srx_stream_t stream) {
+    if (!x || !w || !y) return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || staged_blocks <= 0 || produced_blocks <= 0)
+        return set_error(SRX_ERR_BAD_ARG, "non-positive dimension");
+    if (act != SRX_ACT_NONE && act != SRX_ACT_RELU && act != SRX_ACT_LRELU)
+        return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: activation must be none, relu or leaky relu");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15u)
+        return set_error(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    if (W > 64) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: rows of %d pixels (> 64): use the block-pair launches", W);
+    if ((long)N * H * W * 64 >= (1L << 31) / 4) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: block beyond 32-bit offsets");
+    WideArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.SB = staged_blocks; a.PB = produced_blocks;
+    int th = (16 * kMaxSub) / W;           // <= 128 pixels per unit
+    if (th < 1) th = 1;
+    if (th > H) th = H;
+    a.TH = th;
+    a.RS = W + 1;                          // the zero column left of row r+1 doubles as the right padding of row r
+    a.inv_rs = 1.0f / (float)a.RS;
+    a.tiles_per_img = (H + th - 1) / th;
+    const long units = (long)N * a.tiles_per_img * produced_blocks;
+    if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: too many work units");
+    a.units_total = (int)units;
+    a.act = act;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0 || cus > 256) cus = 256;
+    const int grid = (int)(units < (long)cus ? units : (long)cus);      // one persistent workgroup per CU
+    const size_t lds = ((size_t)(th + 2) * a.RS + 2) * kPS * 4;
+    hipError_t e;
+    if (transpose_filters) e = launch_with_lds(conv_wide_kernel<true>, a, grid, lds, (hipStream_t)stream);
+    else e = launch_with_lds(conv_wide_kernel<false>, a, grid, lds, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(SRX_ERR_LAUNCH, "conv3x3_blocked launch failed: %s", hipGetErrorString(e));
+    return SRX_OK;
+}
