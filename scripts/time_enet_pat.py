@@ -19,7 +19,14 @@ def timeit(fn, k):
     return (time.perf_counter() - t0) / k * 1e3
 tg = timeit(lambda: m.g_step(sd, bq, hd), iters)
 td = timeit(lambda: m.d_step(sd, bq, hd), iters)
-# VGG-19 at 128x128: 2 x 9.78 GMAC... per image forward 6.40 GFLOP; the g run does VGG fwd(sr) + fwd(hd) + dgrad(sr)
-vgg_flop = 3 * 6.40e9 * n
-print('ENet-PAT batch %d x (32->128): g_trainer run %.2f ms (VGG-19 part alone is %.1f GFLOP = %.1f TFLOP/s if it were everything), '
-      'd_trainer run %.2f ms; 3 steps (1 d + 3 g) %.1f ms = %.1f patches/s' % (n, tg, vgg_flop / 1e9, vgg_flop / tg / 1e9, td, td + 3 * tg, 3 * n / ((td + 3 * tg) * 1e-3)))
+# FLOPs of one generator run: VGG-19's 16 convolutions at 128x128 = 6.39 GMAC = 12.78 GFLOP per image and pass, three
+# passes (features of sr and of hd, data gradient of the sr pass); the generator 110,380 MAC per HR pixel forward,
+# twice that backward; the discriminator 0.47 GMAC per image forward + its data gradient
+vgg = 3 * 12.78e9 * n
+gen = 3 * 2 * 110380.0 * 128 * 128 * n
+disc = 2 * 2 * 0.468e9 * n
+flop = vgg + gen + disc
+print('ENet-PAT batch %d x (32->128): g_trainer run %.2f ms = %.1f TFLOP/s (%.0f%% of the fp32-MFMA peak; %.2f TFLOP: VGG-19 %.2f, '
+      'generator %.2f, discriminator %.2f), d_trainer run %.2f ms; one cycle of the schedule (1 d + 3 g runs) %.1f ms = %.1f patches/s'
+      % (n, tg, flop / tg / 1e9, 100 * flop / tg / 1e9 / 157.3, flop / 1e12, vgg / 1e12, gen / 1e12, disc / 1e12, td, td + 3 * tg,
+         3 * n / ((td + 3 * tg) * 1e-3)))
