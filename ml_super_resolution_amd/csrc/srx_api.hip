@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, fused_reduce;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe;
     unsigned long long* trace;
     int dbg;
 };
@@ -37,7 +37,6 @@ Knobs read_knobs() {
     k.stagger = env_int("SRX_STAGGER", -1);
     k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
-    k.fused_reduce = env_int("SRX_FUSED_REDUCE", 1);
     k.trace = nullptr;
     k.dbg = 0;
 #ifdef SRX_TRACE
