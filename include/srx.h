@@ -160,6 +160,17 @@ int srx_act_bwd(const float* dy, const float* y, float* dpre, size_t numel, int 
 int srx_depth_to_space(const float* in, float* out, int N, int H, int W, int C, int r,
                        srx_stream_t stream);
 
+/* ESPCN inference in ONE launch (espcn/espcn/model_espcn.py:117-134 + espcn/espcn/experiment_test.py:171-177):
+ *   t1 = tanh(conv5x5(x; 3->64) + b1), t2 = tanh(conv3x3(t1; 64->32) + b2), y = conv3x3(t2; 32->3 r^2) + b3 (all SAME),
+ *   hr[n, h r + dy, w r + dx, c] = y[n, h, w, (dy r + dx) 3 + c]
+ * x [N,H,W,3], filters HWIO ([5,5,3,64], [3,3,64,32], [3,3,32,3 r^2]), hr [N,H r,W r,3], r in 2..4.  A workgroup chains
+ * the three layers through LDS on a tile of <= 9x9 LR pixels (halo recomputed per tile): meant for latency-bound sizes
+ * such as BASELINE configs[1] (batch 32 of 17x17 patches); for large images the per-layer launches do less work.
+ * Bit-identical to the three srx_conv2d_fwd launches (the last with subpixel_r). */
+int srx_espcn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
+                      srx_stream_t stream);
+
 /* Inverse map (HR image -> sub-pixel label layout): in [N,H*r,W*r,C] -> out [N,H,W,C*r*r].
  * Replaces espcn/espcn/dataset.py:140-156 and espcn/espcn/experiment_test.py:91-96. */
 int srx_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int r,

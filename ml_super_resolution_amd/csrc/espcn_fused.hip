@@ -1,0 +1,274 @@
+// espcn_fused.hip -- ESPCN inference in ONE launch (BASELINE configs[1]: 3x, batch 32 of 17x17 LR patches):
+//   t1 = tanh(conv5x5(x; 3 -> 64) + b1), t2 = tanh(conv3x3(t1; 64 -> 32) + b2), y = conv3x3(t2; 32 -> 3 r^2) + b3,
+//   hr[n, h r + dy, w r + dx, c] = y[n, h, w, (dy r + dx) 3 + c]
+// (espcn/espcn/model_espcn.py:117-134 + espcn/espcn/experiment_test.py:171-177).
+//
+// At that size the three layers are 0.57 GFLOP and three launches are three latency-bound ramps (9 + 14 + 9 us of
+// kernel time plus the gaps between dependent launches).  Here a workgroup owns a tile of <= 9x9 LR output pixels and
+// chains the layers through LDS: the 17x17 input halo, t1 on the tile grown by 2 (13x13 x 64 channels), t2 on the tile
+// grown by 1 (11x11 x 32), then the output straight through the sub-pixel map.  Positions of t1 / t2 outside the image
+// are stored as zeros (SAME padding pads the LAYER INPUT).  Halo pixels are computed by every tile that needs them
+// (f1 x2.1, f2 x1.5 at 9x9 tiles): worth it only while the problem is latency-bound -- the host uses this kernel for
+// small problems and the three-launch path otherwise.  All three filter slices of a wave (25 + 144 + 72 registers) are
+// loaded once per workgroup, exact fp32 on v_mfma_f32_16x16x4_f32; same products and order of accumulation as the
+// per-layer kernels, so the result is bit-identical to them.
+#include <stdarg.h>
+
+#include "../../include/srx.h"
+#include "launchers.h"
+
+namespace srx {
+int set_error(int code, const char* fmt, ...);
+
+namespace {
+
+struct EspcnArgs {
+    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+    float* hr;
+    int N, H, W, r, C3;          // C3 = 3 r^2
+    int T;                       // tile edge (<= 9)
+    int tiles_y, tiles_x, units;
+};
+
+constexpr int kT = 9;                       // largest tile edge
+constexpr int kP1 = 68, kP2 = 36;           // LDS pixel strides of t1 (64 + 4) and t2 (32 + 4) in floats
+constexpr int kX0 = (kT + 8) * (kT + 8) * 4;            // input halo, 4 floats per pixel
+constexpr int kT1 = (kT + 4) * (kT + 4) * kP1;
+constexpr int kT2 = (kT + 2) * (kT + 2) * kP2;
+
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    return v;
+}
+
+template <int NCH3>
+__global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* X0 = lds;
+    float* T1 = lds + kX0;
+    float* T2 = T1 + kT1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    // ---- this wave's filter slices, stationary for the whole kernel
+    // f1: chunk = wave (16 of the 64 channels); k index = input channel kq (3 -> 4: channel 3 is zero)
+    float w1r[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) w1r[t] = (kq < 3) ? a.w1[(t * 3 + kq) * 64 + 16 * wave + li] : 0.f;
+    f32x4 b1r = *reinterpret_cast<const f32x4*>(a.b1 + 16 * wave + 4 * kq);
+    // f2: chunk = wave & 1 (16 of the 32 channels); the two waves of a chunk split the sub-tiles
+    const int ch2 = wave & 1, half2 = wave >> 1;
+    float w2r[144];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w2r[t * 16 + j] = a.w2[(t * 64 + 16 * (j / 4) + 4 * kq + (j % 4)) * 32 + 16 * ch2 + li];
+    f32x4 b2r = *reinterpret_cast<const f32x4*>(a.b2 + 16 * ch2 + 4 * kq);
+    // f3: chunk = wave % NCH3 of ceil(3 r^2 / 16); waves of a chunk split the sub-tiles
+    constexpr int W3 = 4 / NCH3;             // waves per chunk (NCH3 = 3: one each, the fourth wave idles in this phase)
+    const int ch3 = wave % NCH3, part3 = wave / NCH3;
+    const bool on3 = part3 < W3;
+    float w3r[72];
+    {
+        const int co = 16 * ch3 + li;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w3r[t * 8 + j] = (co < a.C3) ? a.w3[(t * 32 + 16 * (j / 4) + 4 * kq + (j % 4)) * a.C3 + co] : 0.f;
+    }
+    float b3r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b3r[e] = (16 * ch3 + 4 * kq + e < a.C3) ? a.b3[16 * ch3 + 4 * kq + e] : 0.f;
+    // sub-pixel store: channel ch -> HR row + ch / (3 r), element + ch % (3 r)   (srx_conv_desc.subpixel_r)
+    const int rc = 3 * a.r, hr_row = a.W * rc;
+    int eo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = 16 * ch3 + 4 * kq + e, dy = ch / rc;
+        eo[e] = dy * hr_row + (ch - dy * rc);
+    }
+
+    for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
+        const int tx_i = u % a.tiles_x, t2_ = u / a.tiles_x;
+        const int ty_i = t2_ % a.tiles_y, n = t2_ / a.tiles_y;
+        const int oy = ty_i * a.T, ox = tx_i * a.T;
+        const int th = (a.H - oy < a.T) ? (a.H - oy) : a.T;
+        const int tw = (a.W - ox < a.T) ? (a.W - ox) : a.T;
+        const int w0 = tw + 8, w1 = tw + 4, w2 = tw + 2;            // region widths: input halo, t1, t2
+        const int n0 = (th + 8) * w0, n1 = (th + 4) * w1, n2 = (th + 2) * w2, n3 = th * tw;
+
+        // ---- stage the input halo (zero outside the image), 4 floats per pixel
+        __syncthreads();
+        for (int p = tid; p < n0; p += 256) {
+            const int r = p / w0, c = p - r * w0;
+            const int ih = oy - 4 + r, iw = ox - 4 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+                const float* px = a.x + (((size_t)n * a.H + ih) * a.W + iw) * 3;
+                v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
+            }
+            *reinterpret_cast<f32x4*>(X0 + p * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- f1: 5x5, 3 -> 64, tanh, on the tile grown by 2; wave = channel chunk, all sub-tiles
+        for (int s0 = 0; s0 * 16 < n1; s0 += 4) {
+            int la[4];
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (s0 + i) + li;
+                const int tt = t < n1 ? t : 0;
+                const int r = tt / w1, c = tt - r * w1;
+                la[i] = (r * w0 + c) * 4 + kq;
+                acc[i] = b1r;
+            }
+#pragma unroll
+            for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    float b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b[i] = X0[la[i] + (kh * w0 + kw) * 4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[kh * 5 + kw], b[i], acc[i], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (s0 + i) + li;
+                if (t < n1) {
+                    const int r = t / w1, c = t - r * w1;
+                    const bool in_img = (unsigned)(oy - 2 + r) < (unsigned)a.H && (unsigned)(ox - 2 + c) < (unsigned)a.W;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(T1 + t * kP1 + 16 * wave + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- f2: 3x3, 64 -> 32, tanh, on the tile grown by 1; wave = (chunk, half of the sub-tiles)
+        for (int s0 = 4 * half2; s0 * 16 < n2; s0 += 8) {
+            int la[4];
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (s0 + i) + li;
+                const int tt = t < n2 ? t : 0;
+                const int r = tt / w2, c = tt - r * w2;
+                la[i] = (r * w1 + c) * kP1 + 4 * kq;
+                acc[i] = b2r;
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + ((tap / 3) * w1 + (tap % 3)) * kP1 + 16 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[tap * 16 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * (s0 + i) + li;
+                if (t < n2) {
+                    const int r = t / w2, c = t - r * w2;
+                    const bool in_img = (unsigned)(oy - 1 + r) < (unsigned)a.H && (unsigned)(ox - 1 + c) < (unsigned)a.W;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(T2 + t * kP2 + 16 * ch2 + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- f3: 3x3, 32 -> 3 r^2, stored through the sub-pixel map; wave = (chunk, share of the sub-tiles)
+        if (on3) {
+            float* hr_img = a.hr + (size_t)n * a.H * a.r * hr_row;
+            for (int s0 = 4 * part3; s0 * 16 < n3; s0 += 4 * W3) {
+                int la[4];
+                f32x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 16 * (s0 + i) + li;
+                    const int tt = t < n3 ? t : 0;
+                    const int r = tt / tw, c = tt - r * tw;
+                    la[i] = (r * w2 + c) * kP2 + 4 * kq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][e] = b3r[e];
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        f32x4 b[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap / 3) * w2 + (tap % 3)) * kP2 + 16 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[tap * 8 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 16 * (s0 + i) + li;
+                    if (t < n3) {
+                        const int r = t / tw, c = t - r * tw;
+                        float* o = hr_img + ((size_t)(oy + r) * a.r * a.W + (ox + c)) * rc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (16 * ch3 + 4 * kq + e < a.C3) o[eo[e]] = acc[i][e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace srx
+
+using namespace srx;
+
+extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
+                                 srx_stream_t stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !hr) return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(SRX_ERR_BAD_ARG, "non-positive dimension");
+    if (r < 2 || r > 4) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: scaling factor %d (2..4 are built)", r);
+    if (((uintptr_t)b1 | (uintptr_t)b2) & 15u) return set_error(SRX_ERR_ALIGN, "bias pointers must be 16-byte aligned");
+    if ((long)N * H * W * 3L * r * r >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: output beyond 32-bit offsets");
+    EspcnArgs a;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.hr = hr;
+    a.N = N; a.H = H; a.W = W; a.r = r; a.C3 = 3 * r * r;
+    // tile edge: the largest that fits, evened out over the image (17 -> 9 + 8, not 9 + 8 by luck: ceil(17 / 2))
+    const int ny = (H + kT - 1) / kT, nx = (W + kT - 1) / kT;
+    int T = (H + ny - 1) / ny;
+    const int Tx = (W + nx - 1) / nx;
+    if (Tx > T) T = Tx;
+    a.T = T;
+    a.tiles_y = (H + T - 1) / T; a.tiles_x = (W + T - 1) / T;
+    const long units = (long)N * a.tiles_y * a.tiles_x;
+    if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: too many tiles");
+    a.units = (int)units;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0 || cus > 256) cus = 256;
+    const int grid = (int)(units < (long)cus ? units : (long)cus);
+    const size_t lds = (size_t)(kX0 + kT1 + kT2) * 4;
+    hipError_t e;
+    const int nch3 = (a.C3 + 15) / 16;
+    if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1>, a, grid, lds, (hipStream_t)stream);
+    else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2>, a, grid, lds, (hipStream_t)stream);
+    else e = launch_with_lds(espcn_fused_kernel<3>, a, grid, lds, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(SRX_ERR_LAUNCH, "espcn_forward launch failed: %s", hipGetErrorString(e));
+    return SRX_OK;
+}

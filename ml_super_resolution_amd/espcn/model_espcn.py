@@ -42,8 +42,13 @@ class EspcnModel(object):
         # inference path: HIP-graph replay of the three launches (SRX_ESPCN_GRAPH=0: eager launches)
         self.use_graph = os.environ.get('SRX_ESPCN_GRAPH', '1') != '0'
         self._graphs = {}
-        self.inference_path = 'f1, f2, f3 with the sub-pixel store fused into its epilogue: 3 launches, no standalone ' \
-                              'depth-to-space pass' + (', replayed as one HIP graph' if self.use_graph else ', eager')
+        # one launch for the whole net while the problem is latency-bound (SRX_ESPCN_FUSED=0: never)
+        self.use_single_launch = os.environ.get('SRX_ESPCN_FUSED', '1') != '0'
+        self.single_launch_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_MAX_PIXELS', '20000'))
+        self.inference_path = ('<= %d LR pixels: ONE launch, the three layers chained through LDS per 9x9 tile with the '
+                               'sub-pixel store (srx_espcn_forward); larger: f1, f2, f3 with the sub-pixel store fused into '
+                               "f3's epilogue, 3 launches%s" % (self.single_launch_max_pixels,
+                                                               ' replayed as one HIP graph' if self.use_graph else ', eager'))
 
     # ---- eager API -----------------------------------------------------------------------------
     def forward(self, lr_source, keep=False):
@@ -62,12 +67,20 @@ class EspcnModel(object):
         return ops.conv2d_fwd(t, st.kernel(2), st.bias(2), 'same', None, subpixel_r=r,
                               out=out if out is not None else st._buf(('sr', 2), (n, h * r, w * r, 3)))
 
-    def super_resolve(self, lr_source, use_graph=None):
+    def super_resolve(self, lr_source, use_graph=None, single_launch=None):
         """The inference path (espcn/espcn/experiment_test.py:156-181: run the net, then the sub-pixel shuffle):
         [N,H,W,3] -> [N,H*r,W*r,3] in three launches -- the f3 layer stores straight through the depth-to-space map
         (bit-identical to super_resolve_two_step) -- replayed as ONE HIP graph per input shape: the problem is
-        launch-latency-bound (0.57 GFLOP at BASELINE configs[1]).  The returned tensor is a buffer owned by the
-        model and overwritten by the next call."""
+        launch-latency-bound (0.57 GFLOP at BASELINE configs[1]).  Small problems (<= single_launch_max_pixels LR
+        pixels) take ONE launch instead: srx_espcn_forward chains the three layers through LDS per 9x9 tile (same
+        bits).  The returned tensor is a buffer owned by the model and overwritten by the next call."""
+        if single_launch is None:
+            single_launch = self.use_single_launch and lr_source.shape[0] * lr_source.shape[1] * lr_source.shape[2] <= self.single_launch_max_pixels
+        if single_launch and lr_source.is_cuda:
+            st, r = self.stack, self.scaling_factor
+            n, h, w, _ = lr_source.shape
+            return ops.espcn_forward(lr_source.contiguous(), [(st.kernel(i), st.bias(i)) for i in range(3)], r,
+                                     out=st._buf(('sr1',), (n, h * r, w * r, 3)))
         if not (self.use_graph if use_graph is None else use_graph) or not lr_source.is_cuda:
             return self._super_resolve_launches(lr_source)
         key = tuple(lr_source.shape)

@@ -158,6 +158,22 @@ def depth_to_space(x, r, out=None):
     return out
 
 
+def espcn_forward(x, params, r, out=None):
+    """ESPCN inference in one launch -- srx_espcn_forward.  params = [(w1, b1), (w2, b2), (w3, b3)] (HWIO kernels);
+    x [N,H,W,3] -> [N,H*r,W*r,3]."""
+    _chk(x, 'x')
+    for k, b in params:
+        _chk(k, 'kernel'); _chk(b, 'bias')
+    (w1, b1), (w2, b2), (w3, b3) = params
+    N, H, W, C = x.shape
+    if C != 3 or tuple(w1.shape) != (5, 5, 3, 64) or tuple(w2.shape) != (3, 3, 64, 32) or tuple(w3.shape) != (3, 3, 32, 3 * r * r):
+        raise ValueError('espcn_forward: shapes do not describe ESPCN 5-3-3 with scaling factor %d' % r)
+    out = out if out is not None else torch.empty((N, H * r, W * r, 3), dtype=torch.float32, device=x.device)
+    check(lib().srx_espcn_forward(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out),
+                                  N, H, W, int(r), _stream()), 'srx_espcn_forward')
+    return out
+
+
 def space_to_depth(x, r, out=None):
     """[N,H*r,W*r,C] -> [N,H,W,C*r*r]."""
     _chk(x, 'x')

@@ -62,16 +62,40 @@ def test_espcn_inference_paths_agree(n, h, w, r):
     g = torch.Generator(device='cuda').manual_seed(102)
     x = torch.rand((n, h, w, 3), device='cuda', generator=g) * 2 - 1
     two = m.super_resolve_two_step(x).clone()
-    eager = m.super_resolve(x, use_graph=False).clone()
-    graph1 = m.super_resolve(x, use_graph=True).clone()
+    eager = m.super_resolve(x, use_graph=False, single_launch=False).clone()
+    graph1 = m.super_resolve(x, use_graph=True, single_launch=False).clone()
     assert two.shape == (n, h * r, w * r, 3)
     assert torch.equal(eager, two) and torch.equal(graph1, two)
     # replay with new data in another buffer, and after an in-place weight update: the graph follows both
     x2 = torch.rand((n, h, w, 3), device='cuda', generator=g) * 2 - 1
-    assert torch.equal(m.super_resolve(x2, use_graph=True), m.super_resolve_two_step(x2))
+    assert torch.equal(m.super_resolve(x2, use_graph=True, single_launch=False), m.super_resolve_two_step(x2))
     m.stack.kernel(2).mul_(0.5)
-    assert torch.equal(m.super_resolve(x2, use_graph=True), m.super_resolve_two_step(x2))
+    assert torch.equal(m.super_resolve(x2, use_graph=True, single_launch=False), m.super_resolve_two_step(x2))
     if n * h * w <= 10000:
         params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
         ref = O.depth_to_space(O.espcn_forward(x2.cpu().numpy(), params), r)
         close(m.super_resolve(x2), ref)
+
+
+@pytest.mark.parametrize('n,h,w,r', [(32, 17, 17, 3), (2, 17, 17, 2), (3, 9, 9, 4), (1, 40, 33, 3), (5, 1, 1, 3), (2, 8, 19, 4),
+                                     (1, 10, 10, 3)],
+                         ids=['config2', 'r2', 'r4_one_tile', 'image_ragged_tiles', 'one_pixel', 'r4_ragged', 'tiles_5x5'])
+def test_espcn_single_launch_equals_three_launches(n, h, w, r):
+    """srx_espcn_forward (the three layers chained through LDS per <= 9x9 tile, one launch) against the per-layer
+    launches: the same products in the same order -> bit-identical; and <= 1e-3 (elementwise bound) against the
+    oracle.  Shapes: exactly BASELINE configs[1]; every scaling factor; tiles that do not divide the image; images
+    smaller than the halo."""
+    from ml_super_resolution_amd.espcn import model_espcn
+    m = model_espcn.EspcnModel(r, device='cuda', seed=200 + r)
+    for i in range(3):
+        m.stack.bias(i).uniform_(-0.1, 0.1)
+    g = torch.Generator(device='cuda').manual_seed(n * 1000 + h * 10 + w)
+    x = torch.rand((n, h, w, 3), device='cuda', generator=g) * 2 - 1
+    one = m.super_resolve(x, single_launch=True).clone()
+    three = m.super_resolve(x, use_graph=False, single_launch=False).clone()
+    assert one.shape == (n, h * r, w * r, 3)
+    assert torch.equal(one, three)
+    params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
+    close(one, O.depth_to_space(O.espcn_forward(x.cpu().numpy(), params), r))
+    # the default route picks the single launch for small problems and the per-layer launches for large ones
+    assert torch.equal(m.super_resolve(x), one)
