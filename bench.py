@@ -237,6 +237,27 @@ def extras(model, dev, stream, x64, y64, px):
     us = hip_event_time_ms(c1, 100, stream) * 1e3
     out['srcnn_c1_us'] = round(us, 2)
     out['srcnn_c1_tflops'] = round(2200e6 / (us * 1e-6) / 1e12, 2)
+    del sm, img, e3, lr
+    # -- BASELINE configs[4] as the reference trains it (enet/enet/experiment_train.py:15-22): EnhanceNet-PAT, batch 64 of
+    #    32x32 -> 128x128 patches, VGG-19 perceptual + texture + adversarial losses (random VGG-shaped weights: the real
+    #    ones are not available offline -- timing only).  One cycle of the schedule = 1 discriminator + 3 generator runs.
+    try:
+        from ml_super_resolution_amd.enet import experiment_train as enet_train, model_enet, model_vgg
+        nb = 64
+        em = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0), device=dev, seed=1)
+        sdb, bqb, hdb = next(enet_train.synthetic_batches(nb, dev))
+        em.g_step(sdb, bqb, hdb); em.d_step(sdb, bqb, hdb)
+        g_ms = hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream)
+        d_ms = hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream)
+        flop = 3 * 12.78e9 * nb + 3 * 2 * 110380.0 * 128 * 128 * nb + 2 * 2 * 0.468e9 * nb
+        out['enet_pat'] = {'batch': nb, 'patch': '32->128', 'g_trainer_ms': round(g_ms, 2), 'd_trainer_ms': round(d_ms, 2),
+                           'patches_per_s': round(3 * nb / ((d_ms + 3 * g_ms) * 1e-3), 1),
+                           'g_trainer_tflops': round(flop / (g_ms * 1e-3) / 1e12, 1),
+                           'g_trainer_frac_of_fp32_mfma_peak': round(flop / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
+                           'weights': 'random VGG-shaped (timing only)'}
+        del em
+    except Exception as exc:             # a secondary number must never take the primary line down
+        out['enet_pat'] = {'error': repr(exc)}
     return out
 
 
