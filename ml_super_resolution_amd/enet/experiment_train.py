@@ -6,6 +6,8 @@ log_path, model='pat', batch_size=64` (:164-170) and the alternating schedule of
   every 3rd step (step % 3 == 0) and if the model has a discriminator: ONE d_trainer run on a batch of its own,
   then always ONE g_trainer run on the next batch (which increments the global step).
 
+A checkpoint (`tf.train.Saver` format and names, model_enet.EnetModel.save_tf_checkpoint) is written whenever
+step % 1000 == 999 (:116-117) and the latest one is restored at start (:96-110).
 Batches are (sd 32x32, bq 128x128, hd 128x128) in [-1, 1] (experiment_train.py:15-22); the reference decodes a
 directory of images on the host (enet/enet/datasets.py); here `--train_dir_path` may be an .npz of {'sd','bq','hd'}
 or absent (synthetic batches).  VGG-19 weights: the .npz the reference downloads (`--vgg19_path`); when it is absent
@@ -35,6 +37,7 @@ def parse_flags(argv=None):
     # not in the reference (its loop never ends): stop after this many generator steps
     ap.add_argument('--stop_training_at_k_step', type=int, default=None)
     ap.add_argument('--allow_random_vgg', default='false')
+    ap.add_argument('--save_every', type=int, default=1000)       # the reference's constant (step % 1000 == 999)
     return ap.parse_args(argv)
 
 
@@ -76,6 +79,13 @@ def main(argv=None, log=None):
             raise SystemExit('VGG-19 weights not found at %r (pass --allow_random_vgg true for a smoke run)' % (FLAGS.vgg19_path,))
         weights = model_vgg.random_vgg_weights(0)
     m = model_enet.EnetModel(FLAGS.model, weights, device=device)
+    # source_ckpt_path = tf.train.latest_checkpoint(FLAGS.ckpt_path); restore if there is one (experiment_train.py:96-110)
+    source = None
+    if FLAGS.ckpt_path and os.path.isdir(FLAGS.ckpt_path):
+        from .. import tf_bundle
+        source = tf_bundle.latest_checkpoint(FLAGS.ckpt_path)
+    if source is not None:
+        m.load_tf_checkpoint(source)
     if world > 1:
         srx_dist.attach_flat(m, world)
     per_rank = FLAGS.batch_size // world
@@ -85,6 +95,10 @@ def main(argv=None, log=None):
         step = m.global_step
         if FLAGS.stop_training_at_k_step is not None and step >= FLAGS.stop_training_at_k_step:
             break
+        if step % FLAGS.save_every == FLAGS.save_every - 1 and FLAGS.ckpt_path and rank == 0:
+            # saver.save(session, ckpt_path/model.ckpt, global_step=step) when step % 1000 == 999 (:116-117)
+            os.makedirs(FLAGS.ckpt_path, exist_ok=True)
+            m.save_tf_checkpoint(os.path.join(FLAGS.ckpt_path, 'model.ckpt-%d' % step))
         # NOTE: train discriminator (experiment_train.py:111-131)
         if step % 3 == 0 and m.discriminator is not None:
             a_loss = m.d_step(*next(batches))

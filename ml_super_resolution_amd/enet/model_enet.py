@@ -401,6 +401,89 @@ class EnetModel(object):
         D.pool.adam_step(lr)
         return self.losses['a_loss']
 
+    # ---- checkpoints (tf.train.Saver format: experiment_train.py:99-110) ------------------------------------------
+    def _named_buffers(self):
+        """[(tf variable name, value view, Adam m view or None, Adam v view or None, to_tf, from_tf)]: kernels are
+        exchanged in TensorFlow's HWIO layout."""
+        G, D = self.generator, self.discriminator
+        gm, gv = self.g_state.get('m'), self.g_state.get('v')
+        out = []
+        ident = (lambda t: t, lambda a, like: a)
+        for i, (k, b) in enumerate(zip(G.kernels, G.biases)):
+            scope = 'g_/conv2d' if i == 0 else 'g_/conv2d_%d' % i
+            for name, t in ((scope + '/kernel', k), (scope + '/bias', b)):
+                off = t.data_ptr() - G.params.data_ptr()
+                sl = lambda buf, off=off, t=t: None if buf is None else buf[off // 4:off // 4 + t.numel()].view(t.shape)
+                out.append((name, t, sl(gm), sl(gv)) + ident)
+        if D is not None:
+            P = D.pool
+            for i, c in enumerate(D.convs):
+                scope = 'd_/conv2d' if i == 0 else 'd_/conv2d_%d' % i
+                to_tf = lambda w, c=c: w.permute(2, 3, 0, 4, 1, 5).reshape(3, 3, c.cin, c.cout)
+                from_tf = lambda a, like, c=c: a.reshape(3, 3, c.cib, c.ci, c.cob, c.co).permute(2, 4, 0, 1, 3, 5)
+                out.append((scope + '/kernel', P.view(2 * i), None if P.opt_m is None else P.view(2 * i, P.opt_m),
+                            None if P.opt_v is None else P.view(2 * i, P.opt_v), to_tf, from_tf))
+                out.append((scope + '/bias', P.view(2 * i + 1), None if P.opt_m is None else P.view(2 * i + 1, P.opt_m),
+                            None if P.opt_v is None else P.view(2 * i + 1, P.opt_v)) + ident)
+            j = 2 * len(D.convs)
+            for i in range(2):
+                scope = 'd_/dense' if i == 0 else 'd_/dense_%d' % i
+                for kind, idx in (('kernel', j + 2 * i), ('bias', j + 2 * i + 1)):
+                    out.append((scope + '/' + kind, P.view(idx), None if P.opt_m is None else P.view(idx, P.opt_m),
+                                None if P.opt_v is None else P.view(idx, P.opt_v)) + ident)
+        return out
+
+    def tf_checkpoint_tensors(self):
+        """{checkpoint key: ndarray} as `tf.train.Saver()` of the reference's training graph names them: the g_ / d_
+        variables (kernels HWIO), `global_step`, and per optimizer the slots `<var>/Adam`, `<var>/Adam_1` with the
+        power accumulators `beta1_power`, `beta2_power` (g_trainer, created first) and `beta1_power_1`,
+        `beta2_power_1` (d_trainer): beta ** (steps + 1), as in engine.ConvStack.tf_checkpoint_tensors.  (Slot and
+        accumulator names as TensorFlow 1.8 is remembered to create them; no TensorFlow-written file to check against.)"""
+        out = {'global_step': np.asarray(self.global_step, dtype=np.int64)}
+        for name, val, m, v, to_tf, _ in self._named_buffers():
+            out[name] = to_tf(val).detach().cpu().numpy()
+            if m is not None:
+                out[name + '/Adam'] = to_tf(m).detach().cpu().numpy()
+                out[name + '/Adam_1'] = to_tf(v).detach().cpu().numpy()
+        if self.g_state:
+            out['beta1_power'] = np.asarray(0.9 ** (self.g_state['t'] + 1), dtype=np.float32)
+            out['beta2_power'] = np.asarray(0.999 ** (self.g_state['t'] + 1), dtype=np.float32)
+        if self.discriminator is not None and self.discriminator.pool.opt_m is not None:
+            out['beta1_power_1'] = np.asarray(0.9 ** (self.discriminator.pool.t + 1), dtype=np.float32)
+            out['beta2_power_1'] = np.asarray(0.999 ** (self.discriminator.pool.t + 1), dtype=np.float32)
+        return out
+
+    def save_tf_checkpoint(self, prefix):
+        from .. import tf_bundle
+        tf_bundle.save_checkpoint(prefix, self.tf_checkpoint_tensors())
+        tf_bundle.update_checkpoint_state(prefix)
+
+    def load_tf_checkpoint(self, prefix):
+        """Restores the g_ / d_ variables, global_step and (when present) both optimizers' state."""
+        from .. import tf_bundle
+        values = tf_bundle.load_checkpoint(prefix)
+        self.global_step = int(values.get('global_step', 0))
+        G, D = self.generator, self.discriminator
+        have_g = 'g_/conv2d/kernel/Adam' in values
+        have_d = D is not None and 'd_/conv2d/kernel/Adam' in values
+        if have_g and not self.g_state:
+            self.g_state.update({'t': 0, 'm': torch.zeros_like(G.params), 'v': torch.zeros_like(G.params)})
+        if have_d and D.pool.opt_m is None:
+            D.pool.opt_m, D.pool.opt_v = torch.zeros_like(D.pool.params), torch.zeros_like(D.pool.params)
+        steps_of = lambda key, beta: int(round(np.log(float(values[key])) / np.log(beta))) - 1
+        if have_g:
+            self.g_state['t'] = steps_of('beta1_power', 0.9) if 'beta1_power' in values else self.global_step
+        if have_d:
+            D.pool.t = steps_of('beta1_power_1', 0.9) if 'beta1_power_1' in values else (self.global_step + 2) // 3
+        for name, val, m, v, _, from_tf in self._named_buffers():
+            if name not in values:
+                raise KeyError('checkpoint %s lacks variable %s' % (prefix, name))
+            put = lambda dst, arr: dst.copy_(from_tf(torch.as_tensor(np.asarray(arr), dtype=torch.float32), dst).to(dst.device))
+            put(val, values[name])
+            if m is not None and name + '/Adam' in values:
+                put(m, values[name + '/Adam'])
+                put(v, values[name + '/Adam_1'])
+
     # ---- Session.run backend ---------------------------------------------------------------------------------------
     def run(self, keys, feed_dict):
         feeds = {name: feed_dict[ph] for name, ph in self.placeholders.items() if ph in feed_dict}
