@@ -276,18 +276,21 @@ int srx_add_relu_grad(const float* a, const float* b, const float* y, float* out
  * adversarial losses: enet/enet/model_enet.py:118-261, enet/enet/model_vgg.py:11-99) -------------------------------- */
 
 /* One launch for a whole 3x3 SAME stride-1 layer wider than 64 channels, on channel-blocked tensors (see
- * srx_conv2d_bwd_data_acc): x [staged_blocks][N,H,W,64] -> y [produced_blocks][N,H,W,64], W <= 64;
+ * srx_conv2d_bwd_data_acc): x [staged_blocks][N,H,W,64] -> y [produced_blocks][N,H,W,64];
  * w = the FORWARD layer's filters as [CIB][COB][3][3][64][64] (block [ib][ob] = HWIO[:, :, 64 ib:64 ib+64, 64 ob:64 ob+64]).
  *   transpose_filters == 0 (forward):  y[ob] = act( sum_ib conv(x[ib], w[ib][ob]) + bias[64 ob ..] ),
  *                                      staged_blocks = CIB, produced_blocks = COB;
  *   transpose_filters != 0 (dgrad):    y[ib] = sum_ob conv(x[ob], flipped / transposed w[ib][ob]),
  *                                      staged_blocks = COB, produced_blocks = CIB, bias NULL, act NONE.
+ * mask (nullable, produced-shaped, blocked): y *= act'(mask) with mask_act -- the activation gradient of the layer
+ * below fused into a data-gradient launch (ReluGrad / leaky-ReLU gradient on its saved post-activation output).
  * Same arithmetic as the block-pair launches (exact fp32 MFMA); the sum over the staged blocks stays in registers.
  * VGG-19 blocks 2-5 and the discriminator's 128..512-channel layers: enet/enet/model_vgg.py:65-99,
- * enet/enet/model_enet.py:118-146.  act: SRX_ACT_NONE / RELU / LRELU. */
-int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
-                        int staged_blocks, int produced_blocks, int act, int transpose_filters,
-                        srx_stream_t stream);
+ * enet/enet/model_enet.py:118-146.  act: SRX_ACT_NONE / RELU / LRELU.  Any image width (rows wider than 64 pixels are
+ * cut into column strips). */
+int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, const float* mask, int mask_act, float* y,
+                        int N, int H, int W, int staged_blocks, int produced_blocks, int act,
+                        int transpose_filters, srx_stream_t stream);
 
 /* tf.nn.max_pool(ksize 2x2, strides 2x2, padding='SAME') (enet/enet/model_vgg.py:28-36): [N,H,W,C] ->
  * [N,ceil(H/2),ceil(W/2),C], C % 4 == 0.  _bwd = MaxPoolGrad given the forward INPUT x: the gradient of a window goes

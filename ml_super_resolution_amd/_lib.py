@@ -101,7 +101,7 @@ def lib():
     L.srx_add_relu_grad.argtypes = [vp, vp, vp, vp, sz, vp]
     L.srx_conv2d_bwd_data_acc.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
     L.srx_espcn_forward.argtypes = [vp] * 8 + [i, i, i, i, vp]
-    L.srx_conv3x3_blocked.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    L.srx_conv3x3_blocked.argtypes = [vp, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
     L.srx_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
     L.srx_maxpool2x2_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.srx_subsample2.argtypes = [vp, vp, i, i, i, i, i, i, vp]

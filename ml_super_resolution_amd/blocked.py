@@ -132,7 +132,7 @@ class BlockedConv(object):
         return self._subsampled(y) if self.stride == 2 else y
 
     def _wide_ok(self, width):
-        return (USE_WIDE and (self.cib > 1 or self.cob > 1) and self.ci == 64 and self.co == 64 and width <= 64 and
+        return (USE_WIDE and (self.cib > 1 or self.cob > 1) and self.ci == 64 and self.co == 64 and
                 self.act in (None, 'relu', 'lrelu', 'leaky_relu'))
 
     def _subsampled(self, y):
@@ -152,19 +152,27 @@ class BlockedConv(object):
             ops.subsample2_bwd(dpre[ob], 1, 1, out=full[ob])
         return full
 
-    def dgrad(self, dpre):
+    def dgrad(self, dpre, mask=None, mask_act=None):
         """dpre [COB, N, OH, OW, co] (gradient w.r.t. the layer's pre-activation output) -> dx [CIB, N, H, W, ci],
-        the gradient w.r.t. the layer's input (no activation mask applied)."""
+        the gradient w.r.t. the layer's input.  mask / mask_act: the layer's INPUT as saved (the post-activation
+        output of the layer below) and that layer's activation -- the result is then already multiplied by the
+        activation gradient (ReluGrad / leaky-ReLU gradient), fused into the launch where the kernel allows."""
         dp = self._full_res(dpre)
         _, n, h, w, _ = dp.shape
         dx = torch.empty((self.cib, n, h, w, self.ci), dtype=torch.float32, device=dp.device)
         if self._wide_ok(w):
-            return ops.conv3x3_blocked(dp, self.w, None, None, transpose=True, out=dx)
+            return ops.conv3x3_blocked(dp, self.w, None, None, transpose=True, out=dx, mask=mask, mask_act=mask_act)
         xs = (n, h, w, self.ci)
+        if self.cob == 1 and mask is not None:
+            for ib in range(self.cib):
+                ops.conv2d_bwd_data(dp[0], self.w[ib, 0], xs, 'same', x_in=mask[ib], in_act=mask_act, out=dx[ib])
+            return dx
         for ib in range(self.cib):
             ops.conv2d_bwd_data(dp[0], self.w[ib, 0], xs, 'same', out=dx[ib])
             for ob in range(1, self.cob):
                 ops.conv2d_bwd_data_acc(dp[ob], self.w[ib, ob], xs, dx[ib], 'same', out=dx[ib])
+            if mask is not None:
+                ops.act_bwd(dx[ib], mask[ib], mask_act, out=dx[ib])
         return dx
 
     def wgrad(self, x, dpre):

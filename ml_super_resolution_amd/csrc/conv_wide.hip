@@ -26,10 +26,12 @@ struct WideArgs {
     const float* w;      // blocked filters [CIB][COB][9][64][64] of the FORWARD layer
     const float* bias;   // [PB*64] or null
     float* y;            // produced tensor, PB blocks of [N,H,W,64]
+    const float* mask;   // produced-shaped or null: y *= act'(mask) with mask_act (the activation gradient of the layer below)
     int N, H, W, SB, PB;
-    int TH, RS, tiles_per_img, units_total;
+    int TH, TW, RS, tiles_y, tiles_x, units_total;
     float inv_rs;
     int act;             // fused after the sum over the staged blocks: NONE / RELU / LRELU
+    int mask_act;
 };
 
 constexpr int kPS = 68;          // LDS pixel stride in floats (64 + 4: conflict-free ds_read_b128 over 16 pixels)
@@ -76,11 +78,14 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
     for (int u = u0; u < u1; ++u) {
         // units of one tile are adjacent (the produced blocks re-read the same staged tiles: L2 serves them)
         const int pb = u % a.PB;
-        const int tile = u / a.PB;
-        const int n = tile / a.tiles_per_img;
-        const int h0 = (tile % a.tiles_per_img) * a.TH;
+        int tile = u / a.PB;
+        const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+        const int n = tile / a.tiles_y;
+        const int h0 = (tile % a.tiles_y) * a.TH;
+        const int ox = tx * a.TW;
         const int th = (a.H - h0 < a.TH) ? (a.H - h0) : a.TH;
-        const int npx = th * a.W;
+        const int tw = (a.W - ox < a.TW) ? (a.W - ox) : a.TW;
+        const int npx = th * tw;
         const int n_sub = (npx + 15) >> 4;
         const int n_need = (th + 2) * a.RS + 2;
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
         f32x4 acc0[4], acc1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc0[i] = bias4; acc1[i] = bias4; }
-        const float inv_w = 1.0f / (float)a.W;
+        const float inv_w = 1.0f / (float)tw;
         // lane's pixel of sub-tile i -> LDS address of its (tap 0,0) slot (sub-tiles past the tile compute on pixel 0 and
         // are not stored).  Recomputed per group rather than kept: the kernel sits at the 256-register limit of two
         // waves per SIMD (144 filter registers + 32 accumulators + 32 LDS fragments), and a dozen integer
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int t = 16 * (first + i) + li;
                 const int tt = (t < npx) ? t : 0;
-                const int orow = fdiv_small(tt, inv_w, a.W);
-                const int ocol = tt - orow * a.W;
+                const int orow = fdiv_small(tt, inv_w, tw);
+                const int ocol = tt - orow * tw;
                 la[i] = (orow * a.RS + ocol) * kPS + 4 * kq;
             }
         };
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
             // first and land while the tile is staged.
             load_stationary_weights<9, 64, WT>(wr, wa, cout0, li, kq);
             lds_barrier();                                                     // every wave is done with the previous tile
-            stage_tile<64>(lds, a.x + (size_t)sb * blk_elems, n, a.H, a.W, 64, h0 - 1, -1, a.RS, a.inv_rs, n_need, tid);
+            stage_tile<64>(lds, a.x + (size_t)sb * blk_elems, n, a.H, a.W, 64, h0 - 1, ox - 1, a.RS, a.inv_rs, n_need, tid);
             lds_barrier();
             __builtin_amdgcn_s_setprio(0);
             {
@@ -132,21 +137,26 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
         }
         // MFMA results are read by VALU code next: software covers the result latency
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-        float* yb = a.y + (size_t)pb * blk_elems + (size_t)n * a.H * a.W * 64 + (size_t)h0 * a.W * 64 + cout0 + 4 * kq;
-        const float slope = act_slope(a.act);
-        // pixel t of the tile is pixel t of the image rows h0.. (full-width tiles): its output offset is t * 64
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = 16 * i + li;
-            if (t < npx) *reinterpret_cast<f32x4*>(yb + t * 64) = act_apply4(acc0[i], a.act, slope);
-        }
-        if (n_sub > 4) {
+        const size_t img_off = (size_t)pb * blk_elems + (size_t)n * a.H * a.W * 64 + cout0 + 4 * kq;
+        float* yb = a.y + img_off;
+        const float* mb = a.mask ? a.mask + img_off : nullptr;
+        const float slope = act_slope(a.act), mslope = act_slope(a.mask_act);
+        auto store = [&](int first, const f32x4 (&acc)[4]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int t = 16 * (i + 4) + li;
-                if (t < npx) *reinterpret_cast<f32x4*>(yb + t * 64) = act_apply4(acc1[i], a.act, slope);
+                const int t = 16 * (first + i) + li;
+                if (t < npx) {
+                    const int orow = fdiv_small(t, inv_w, tw);
+                    const int ocol = t - orow * tw;
+                    const size_t o = ((size_t)(h0 + orow) * a.W + ox + ocol) * 64;
+                    f32x4 v = act_apply4(acc[i], a.act, slope);
+                    if (mb) v = act_grad4(v, *reinterpret_cast<const f32x4*>(mb + o), a.mask_act, mslope);
+                    *reinterpret_cast<f32x4*>(yb + o) = v;
+                }
             }
-        }
+        };
+        store(0, acc0);
+        if (n_sub > 4) store(4, acc1);
     }
 }
 
@@ -155,29 +165,38 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const WideArgs a) {
 
 using namespace srx;
 
-extern "C" int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
-                                   int staged_blocks, int produced_blocks, int act, int transpose_filters,
-                                   srx_stream_t stream) {
+extern "C" int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, const float* mask, int mask_act,
+                                   float* y, int N, int H, int W, int staged_blocks, int produced_blocks, int act,
+                                   int transpose_filters, srx_stream_t stream) {
     if (!x || !w || !y) return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
     if (N <= 0 || H <= 0 || W <= 0 || staged_blocks <= 0 || produced_blocks <= 0)
         return set_error(SRX_ERR_BAD_ARG, "non-positive dimension");
     if (act != SRX_ACT_NONE && act != SRX_ACT_RELU && act != SRX_ACT_LRELU)
         return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: activation must be none, relu or leaky relu");
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15u)
+    if (mask && (mask_act < SRX_ACT_NONE || mask_act > SRX_ACT_SIGMOID)) return set_error(SRX_ERR_BAD_ARG, "bad mask_act");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)mask) & 15u)
         return set_error(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
-    if (W > 64) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: rows of %d pixels (> 64): use the block-pair launches", W);
+    if (mask == y) return set_error(SRX_ERR_BAD_ARG, "conv3x3_blocked: the mask operand cannot alias the output");
     if ((long)N * H * W * 64 >= (1L << 31) / 4) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: block beyond 32-bit offsets");
     WideArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.mask = mask; a.mask_act = mask ? mask_act : 0;
     a.N = N; a.H = H; a.W = W; a.SB = staged_blocks; a.PB = produced_blocks;
-    int th = (16 * kMaxSub) / W;           // <= 128 pixels per unit
+    // <= 128 pixels per unit.  Rows of up to 64 pixels: full-width tiles (the zero column left of row r+1 doubles as the
+    // right padding of row r); wider images: column strips of 64 with their own halo columns.
+    int tw = W <= 64 ? W : 64;
+    if (W > 64) {                          // even the strips out: 130 -> 44 + 43 + 43, not 64 + 64 + 2
+        const int nx = (W + 63) / 64;
+        tw = (W + nx - 1) / nx;
+    }
+    int th = (16 * kMaxSub) / tw;
     if (th < 1) th = 1;
     if (th > H) th = H;
-    a.TH = th;
-    a.RS = W + 1;                          // the zero column left of row r+1 doubles as the right padding of row r
+    a.TH = th; a.TW = tw;
+    a.RS = W <= 64 ? W + 1 : tw + 2;
     a.inv_rs = 1.0f / (float)a.RS;
-    a.tiles_per_img = (H + th - 1) / th;
-    const long units = (long)N * a.tiles_per_img * produced_blocks;
+    a.tiles_y = (H + th - 1) / th;
+    a.tiles_x = (W + tw - 1) / tw;
+    const long units = (long)N * a.tiles_y * a.tiles_x * produced_blocks;
     if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "conv3x3_blocked: too many work units");
     a.units_total = (int)units;
     a.act = act;

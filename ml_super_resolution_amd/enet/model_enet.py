@@ -264,16 +264,22 @@ class Discriminator(object):
         dflat = self.dense[0].backward(flat, h, dh, want_dx=True, want_dw=want_dw)
         last = acts[-1]
         g = to_blocks(dflat.view(last.shape[1], last.shape[2], last.shape[3], -1))
+        masked = False                 # g already carries the leaky-ReLU gradient of the layer it belongs to
         for i in range(len(self.convs) - 1, -1, -1):
             c, y = self.convs[i], acts[i + 1]
-            dpre = torch.empty_like(g)
-            for b in range(g.shape[0]):
-                ops.act_bwd(g[b], y[b], 'lrelu', out=dpre[b])
+            if masked:
+                dpre = g
+            else:
+                dpre = torch.empty_like(g)
+                for b in range(g.shape[0]):
+                    ops.act_bwd(g[b], y[b], 'lrelu', out=dpre[b])
             if want_dw:
                 c.wgrad(acts[i], dpre)
             if i == 0 and not want_dx:
                 return None
-            g = c.dgrad(dpre)
+            # the activation gradient of layer i - 1 (whose output acts[i] is this layer's input) rides in the launch
+            g = c.dgrad(dpre, mask=acts[i] if i > 0 else None, mask_act='lrelu' if i > 0 else None)
+            masked = i > 0
         return to_nhwc(g)
 
 

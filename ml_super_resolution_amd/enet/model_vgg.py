@@ -112,26 +112,35 @@ class Vgg19(object):
         feats = self._saved
         if feats is None:
             raise RuntimeError('backward() needs a forward(..., keep=True) first')
-        g = None
+        def relu_grad(t, y):                                               # ReluGrad on the post-ReLU tensor
+            out = torch.empty_like(t)
+            for b in range(t.shape[0]):
+                ops.act_bwd(t[b], y[b], 'relu', out=out[b])
+            return out
+
+        g, masked = None, False        # masked: g is already multiplied by ReluGrad of the layer it belongs to
         for idx in range(len(LAYER_NAMES) - 1, -1, -1):
             name = LAYER_NAMES[idx]
             if name in dtaps:
                 d = to_blocks(dtaps[name])
+                if masked:
+                    d = relu_grad(d, feats[name])
                 g = d if g is None else ops_add_(g, d)
             if g is None:
                 continue
-            below = feats[LAYER_NAMES[idx - 1]] if idx > 0 else feats['input']
+            below_name = LAYER_NAMES[idx - 1] if idx > 0 else 'input'
+            below = feats[below_name]
             if name.endswith('pool'):
                 dx = torch.empty_like(below)
                 for b in range(below.shape[0]):
                     ops.maxpool2x2_bwd(below[b], g[b], out=dx[b])
-                g = dx
+                g, masked = dx, False
             else:
-                y = feats[name]
-                dpre = torch.empty_like(g)
-                for b in range(g.shape[0]):
-                    ops.act_bwd(g[b], y[b], 'relu', out=dpre[b])          # ReluGrad on the post-ReLU tensor
-                g = self.layers[name].dgrad(dpre)
+                dpre = g if masked else relu_grad(g, feats[name])
+                # the ReluGrad of the conv layer below rides in this layer's data-gradient launch
+                fuse = 'conv' in below_name
+                g = self.layers[name].dgrad(dpre, mask=below if fuse else None, mask_act='relu' if fuse else None)
+                masked = fuse
         return ops.vgg_preprocess(to_nhwc(g).contiguous(), backward=True)
 
 

@@ -335,19 +335,21 @@ def conv2d_bwd_data_acc(dpre, w, x_shape, dx_acc, padding='same', out=None):
     return dx
 
 
-def conv3x3_blocked(x, w, bias=None, act=None, transpose=False, out=None):
+def conv3x3_blocked(x, w, bias=None, act=None, transpose=False, out=None, mask=None, mask_act=None):
     """A whole 3x3 SAME layer wider than 64 channels in one launch -- srx_conv3x3_blocked.
     x [SB, N, H, W, 64]; w [CIB, COB, 3, 3, 64, 64] (the forward layer's filters); forward: SB = CIB, result
     [COB, N, H, W, 64] = act(sum + bias); transpose=True (data gradient): SB = COB, result [CIB, N, H, W, 64]."""
-    _chk(x, 'x'); _chk(w, 'w'); _chk(bias, 'bias')
+    _chk(x, 'x'); _chk(w, 'w'); _chk(bias, 'bias'); _chk(mask, 'mask')
     sb, n, h, wd, c = x.shape
     cib, cob = w.shape[0], w.shape[1]
     if c != 64 or tuple(w.shape[2:]) != (3, 3, 64, 64) or sb != (cob if transpose else cib):
         raise ValueError('conv3x3_blocked: x %s does not fit filters %s' % (tuple(x.shape), tuple(w.shape)))
     pb = cib if transpose else cob
     out = out if out is not None else torch.empty((pb, n, h, wd, 64), dtype=torch.float32, device=x.device)
-    check(lib().srx_conv3x3_blocked(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, h, wd, sb, pb, ACT_BY_NAME[act],
-                                    int(transpose), _stream()), 'srx_conv3x3_blocked')
+    if mask is not None and tuple(mask.shape) != tuple(out.shape):
+        raise ValueError('conv3x3_blocked: mask %s does not have the result shape %s' % (tuple(mask.shape), tuple(out.shape)))
+    check(lib().srx_conv3x3_blocked(_ptr(x), _ptr(w), _ptr(bias), _ptr(mask), ACT_BY_NAME[mask_act], _ptr(out), n, h, wd, sb, pb,
+                                    ACT_BY_NAME[act], int(transpose), _stream()), 'srx_conv3x3_blocked')
     return out
 
 

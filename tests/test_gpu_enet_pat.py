@@ -392,7 +392,8 @@ def test_generic_kernel_without_aux_operand(n, hw, cin, cout):
 
 
 @pytest.mark.parametrize('cin,cout,hw,n,act', [(128, 128, 8, 3, 'relu'), (512, 512, 4, 2, 'lrelu'), (256, 128, 33, 1, None),
-                                               (128, 256, 64, 1, 'relu'), (192, 64, 7, 2, 'relu'), (64, 192, 16, 2, 'lrelu')])
+                                               (128, 256, 64, 1, 'relu'), (192, 64, 7, 2, 'relu'), (64, 192, 16, 2, 'lrelu'),
+                                               (128, 128, 130, 1, 'relu'), (128, 64, 65, 1, 'lrelu')])
 def test_one_launch_wide_layer_equals_block_pair_launches(cin, cout, hw, n, act):
     """srx_conv3x3_blocked (one launch, the sum over the input blocks in registers) against the block-pair launches of
     the 64-channel kernels (the running sum through memory) and against the oracle: forward and data gradient."""
@@ -421,6 +422,17 @@ def test_one_launch_wide_layer_equals_block_pair_launches(cin, cout, hw, n, act)
     close(blocked.to_nhwc(d1), dref); close(blocked.to_nhwc(d0), dref)
     # same products, but the partial sums of the block-pair route are rounded to fp32 between launches
     assert float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    # the activation gradient of the layer below fused into the data-gradient launch (mask = the layer's saved input)
+    for mact in ('relu', 'lrelu'):
+        xm = blocked.to_blocks(dev(np.where(rng.uniform(size=x.shape) < 0.5, x, 0).astype(np.float32)))
+        want = blocked.to_nhwc(d1) * torch.from_numpy(O.act_grad_from_y(_np(blocked.to_nhwc(xm)).astype(np.float64), mact)).float().cuda()
+        for wide in (True, False):
+            blocked.USE_WIDE = wide
+            try:
+                got = layer.dgrad(dpb, mask=xm, mask_act=mact)
+            finally:
+                blocked.USE_WIDE = old
+            close(blocked.to_nhwc(got), _np(want).astype(np.float64))
 
 
 def test_enet_train_script_checkpoint_and_resume(tmp_path):
