@@ -406,7 +406,9 @@ def main():
         }
         if allreduce_ms is not None:
             line['allreduce_ms'] = round(allreduce_ms, 4)
-        if not args.no_extras:
+        if not args.no_extras and world == 1:
+            # (N = 1 only, like the CPU baselines: the other ranks of an N > 1 run would sit in process-group teardown
+            # while rank 0 measured them)
             line.update(extras(model, dev, stream, x64, y64, px))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rank)
