@@ -193,6 +193,50 @@ def make_nets():
     np.savez_compressed(os.path.join(HERE, 'nets.npz'), **out)
 
 
+def enet_pat_case(seed=21, vgg_width=8, d_width=32, size=64, units=32, n=2):
+    """Seeded inputs and weights of the committed EnhanceNet-PAT fixture (regenerated from the seed by the tests):
+    VGG-19-shaped net of width 8, discriminator of the reference's widths on 64x64 images."""
+    from oracle import oracle_enet as E
+    rng = np.random.default_rng(seed)
+    vgg = {}
+    for name, (cin, cout) in E.vgg19_channels(vgg_width).items():
+        k = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (3, 3, cin, cout)).astype(np.float32)
+        if name == 'block1_conv1':
+            k /= np.float32(60.0)
+        vgg[name] = (k, rng.normal(0, 0.05, cout).astype(np.float32))
+    convs, cin = [], 3
+    for i in range(5):
+        f = d_width * 2 ** i
+        for _ in range(2):
+            convs.append((rng.normal(0, np.sqrt(1.5 / (9 * cin)), (3, 3, cin, f)).astype(np.float32),
+                          rng.normal(0, 0.05, f).astype(np.float32)))
+            cin = f
+    feat = (size // 32) ** 2 * cin
+    dense = [(rng.normal(0, np.sqrt(1.0 / feat), (feat, units)).astype(np.float32), rng.normal(0, 0.05, units).astype(np.float32)),
+             (rng.normal(0, np.sqrt(1.0 / units), (units, 1)).astype(np.float32), rng.normal(0, 0.05, 1).astype(np.float32))]
+    hd = rng.uniform(-1, 1, (n, size, size, 3)).astype(np.float32)
+    sr = np.clip(hd + rng.normal(0, 0.2, hd.shape), -1, 1).astype(np.float32)
+    return vgg, convs, dense, sr, hd
+
+
+def make_enet_pat():
+    """enet_pat.npz: the CONTINUOUS quantities of EnhanceNet-PAT's loss side from oracle/oracle_enet.py (VGG-19
+    features, discriminator outputs, the five losses of build_enet) for enet_pat_case().  Gradients are compared
+    against the oracle at run time (they are discontinuous in the activations: see tests/test_gpu_enet_pat.py)."""
+    from oracle import oracle_enet as E
+    vgg, convs, dense, sr, hd = enet_pat_case()
+    feats = E.vgg19_forward(sr, vgg)
+    losses, _ = E.enet_losses_and_sr_gradient(sr, hd, vgg, convs, dense, 'pat')
+    out = {'sr': sr, 'hd': hd}
+    for name in ('block1_conv1', 'block2_pool', 'block3_conv1', 'block5_pool'):
+        out['vgg.' + name] = feats[name].astype(np.float32)
+    out['d.fake'] = E.discriminator_forward(sr, convs, dense).astype(np.float32)
+    out['d.real'] = E.discriminator_forward(hd, convs, dense).astype(np.float32)
+    for k, v in losses.items():
+        out['loss.' + k] = np.float64(v)
+    np.savez_compressed(os.path.join(HERE, 'enet_pat.npz'), **out)
+
+
 def make_d2s_maps():
     out = {}
     for r in (2, 3, 4):
@@ -206,6 +250,7 @@ def make_d2s_maps():
 
 if __name__ == '__main__':
     make_pins()
+    make_enet_pat()
     make_ops()
     make_nets()
     make_d2s_maps()
