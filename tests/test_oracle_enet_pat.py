@@ -161,3 +161,17 @@ def test_vgg19_structure():
     ch = E.vgg19_channels(64)
     assert len(ch) == 16 and ch['block1_conv1'] == (3, 64) and ch['block3_conv1'] == (128, 256)
     assert ch['block4_conv1'] == (256, 512) and ch['block5_conv4'] == (512, 512)
+
+
+def test_committed_fixture_is_what_the_oracle_computes():
+    """tests/golden/enet_pat.npz freezes oracle/oracle_enet.py for the seeded case of make_golden.enet_pat_case()."""
+    import os
+    from tests.golden.make_golden import enet_pat_case
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'enet_pat.npz'))
+    vgg, convs, dense, sr, hd = enet_pat_case()
+    feats = E.vgg19_forward(sr, vgg)
+    for name in ('block1_conv1', 'block2_pool', 'block3_conv1', 'block5_pool'):
+        np.testing.assert_allclose(feats[name], z['vgg.' + name], rtol=0, atol=1e-5 * np.abs(feats[name]).max())
+    losses, _ = E.enet_losses_and_sr_gradient(sr, hd, vgg, convs, dense, 'pat')
+    for k, v in losses.items():
+        np.testing.assert_allclose(v, float(z['loss.' + k]), rtol=1e-12)
