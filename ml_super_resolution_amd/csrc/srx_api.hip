@@ -124,6 +124,11 @@ int make_plan(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, 
     // full-width tiles: the zero column(s) left of row r+1 double as the right padding of row r
     int RS = W + pad_l;
     if (RS < OW + KW - 1 - (KW - 1 - pad_l)) RS = OW + pad_l;
+    // A tile row holds the OW + KW - 1 input columns from -pad_l on; what does not fit wraps into the next row's
+    // pad_l leading zero slots.  Even filter sizes with SAME padding pad one more column AFTER than before (TF:
+    // pad_before = (K-1)/2), so their rows need one slot more than W + pad_l (round 2: found by the extended shape
+    // sweep -- 2x2 / 4x4 SAME read the next row's first pixel as right padding).
+    if (RS < OW + KW - 1 - pad_l) RS = OW + KW - 1 - pad_l;
     int TW = OW, NTX = 1;
     long th_max = ((long)max_slots - (KW - 1)) / RS - (KH - 1);
     const int kMaxGrid = max_grid();

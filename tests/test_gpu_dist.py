@@ -98,6 +98,31 @@ def test_two_ranks_equal_single_process(tmp_path, use_adam):
     np.testing.assert_allclose(0.5 * (r0['losses'][0] + r1['losses'][0]), one['losses'][0], rtol=2e-6)
 
 
+def test_enet_two_ranks_equal_single_process(tmp_path):
+    """EnhanceNet-PAT data parallel (dist.attach_flat): both trainers' gradients averaged over two ranks equal the
+    single-process gradients of the concatenated batch (every loss of build_enet is a mean over the batch), replicas
+    stay bit-identical, the parameters after one d run + one g run agree."""
+    d2 = tmp_path / 'w2'
+    d2.mkdir()
+    r0, r1 = _run_ranks(d2, 2, ['enet', 4])
+    d1 = tmp_path / 'w1'
+    d1.mkdir()
+    one = _single(d1, ['enet', 4])
+    for key in ('g_params', 'd_params', 'g_grad', 'd_grad'):
+        np.testing.assert_array_equal(r0[key], r1[key], err_msg=key)
+    assert int(r0['global_step']) == int(one['global_step']) == 1
+    for key in ('g_grad', 'd_grad'):
+        ref = one[key]
+        assert np.abs(r0[key] - ref).max() <= 5e-5 * np.abs(ref).max(), (key, np.abs(r0[key] - ref).max() / np.abs(ref).max())
+    np.testing.assert_allclose(0.5 * (r0['a_loss'] + r1['a_loss']), one['a_loss'], rtol=1e-5)
+    np.testing.assert_allclose(0.5 * (r0['g_loss_all'] + r1['g_loss_all']), one['g_loss_all'], rtol=1e-4)
+    # Adam(1e-4): no element moves further than lr per step; where the gradient is not tiny the updates agree
+    for pk, gk in (('g_params', 'g_grad'), ('d_params', 'd_grad')):
+        assert np.abs(r0[pk] - one[pk]).max() <= 2.1e-4
+        big = np.abs(one[gk]) > 1e-3 * np.abs(one[gk]).max()
+        assert np.abs(r0[pk] - one[pk])[big].max() <= 2e-6 * max(np.abs(one[pk]).max(), 1.0)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two fresh ranks (gloo on a
     one-GPU box), rank 0 prints ONE JSON line with the contract's keys."""

@@ -495,3 +495,18 @@ def test_enet_pat_against_committed_golden_vectors():
     for k in ('p_loss', 't_loss', 'g_loss', 'a_loss', 'g_loss_all'):
         ref = float(z['loss.' + k])
         assert abs(m.losses[k].item() - ref) <= 2e-4 * abs(ref), (k, m.losses[k].item(), ref)
+
+
+@pytest.mark.parametrize('k,cin,cout,h,w', [(2, 16, 16, 14, 9), (4, 32, 8, 11, 13), (2, 3, 64, 6, 6), (4, 64, 64, 9, 20)])
+def test_even_filter_sizes_with_same_padding(k, cin, cout, h, w):
+    """Regression (round 2, found by scripts/fuzz_conv.py): TF SAME pads (K-1)/2 before and the rest after, so an even
+    filter pads one more column on the right; the tile rows were one slot short for that and read the next row's first
+    pixel instead of zero.  (No layer of the reference has an even filter; the C ABI accepts any KH x KW.)"""
+    from ml_super_resolution_amd import ops
+    rng = np.random.default_rng(k * 100 + cin)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    wt = rng.normal(0, 1.0 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
+    b = rng.normal(0, 0.1, cout).astype(np.float32)
+    close(ops.conv2d_fwd(dev(x), dev(wt), dev(b), 'same', 'relu'), O.conv2d_fwd(x, wt, b, 'SAME', 'relu'))
+    dpre = rng.normal(size=(2, h, w, cout)).astype(np.float32)
+    close(ops.conv2d_bwd_data(dev(dpre), dev(wt), x.shape, 'same'), O.conv2d_bwd_data(dpre, wt, (h, w), 'SAME'))
