@@ -59,11 +59,14 @@ class EspcnModel(object):
         """forward + the standalone depth-to-space pass (4 launches): [N,H,W,3] -> [N,H*r,W*r,3]."""
         return ops.depth_to_space(self.forward(lr_source), self.scaling_factor)
 
-    def _super_resolve_launches(self, lr_source, out=None):
+    def _super_resolve_launches(self, lr_source, out=None, mids=None):
+        """mids: the two intermediate tensors to use (a captured graph owns its own: the shared ones below are
+        replaced when another image size comes along, and a replay must never write through a dangling pointer)."""
         st, r = self.stack, self.scaling_factor
         n, h, w, _ = lr_source.shape
-        t = ops.conv2d_fwd(lr_source, st.kernel(0), st.bias(0), 'same', 'tanh', out=st._buf(('sr', 0), (n, h, w, 64)))
-        t = ops.conv2d_fwd(t, st.kernel(1), st.bias(1), 'same', 'tanh', out=st._buf(('sr', 1), (n, h, w, 32)))
+        t1, t2 = mids if mids is not None else (st._buf(('sr', 0), (n, h, w, 64)), st._buf(('sr', 1), (n, h, w, 32)))
+        t = ops.conv2d_fwd(lr_source, st.kernel(0), st.bias(0), 'same', 'tanh', out=t1)
+        t = ops.conv2d_fwd(t, st.kernel(1), st.bias(1), 'same', 'tanh', out=t2)
         return ops.conv2d_fwd(t, st.kernel(2), st.bias(2), 'same', None, subpixel_r=r,
                               out=out if out is not None else st._buf(('sr', 2), (n, h * r, w * r, 3)))
 
@@ -87,7 +90,7 @@ class EspcnModel(object):
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = self._capture(lr_source)
-        static_in, graph_obj, out = g
+        static_in, graph_obj, out = g[:3]
         if lr_source.data_ptr() != static_in.data_ptr():
             static_in.copy_(lr_source)
         graph_obj.replay()
@@ -103,16 +106,18 @@ class EspcnModel(object):
         n, h, w, _ = lr_source.shape
         r = self.scaling_factor
         out = torch.empty((n, h * r, w * r, 3), dtype=torch.float32, device=lr_source.device)
+        mids = (torch.empty((n, h, w, 64), dtype=torch.float32, device=lr_source.device),
+                torch.empty((n, h, w, 32), dtype=torch.float32, device=lr_source.device))
         side = torch.cuda.Stream(device=lr_source.device)
         side.wait_stream(torch.cuda.current_stream(lr_source.device))
         with torch.cuda.stream(side):
             for _ in range(2):
-                self._super_resolve_launches(static_in, out=out)
+                self._super_resolve_launches(static_in, out=out, mids=mids)
         torch.cuda.current_stream(lr_source.device).wait_stream(side)
         graph_obj = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_obj):
-            self._super_resolve_launches(static_in, out=out)
-        return static_in, graph_obj, out
+            self._super_resolve_launches(static_in, out=out, mids=mids)
+        return static_in, graph_obj, out, mids          # (the tuple keeps every buffer the graph points at alive)
 
     def train_step(self, lr_source, hr_target, learning_rate):
         """MSE in sub-pixel space (hr_target is the space-to-depth label, dataset.py:140-156) + Adam
