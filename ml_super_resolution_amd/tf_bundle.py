@@ -290,6 +290,52 @@ def snappy_decompress(buf):
     return bytes(out)
 
 
+def snappy_compress(data):
+    """A small Snappy (raw block format) compressor: greedy matching of 4-byte sequences through a hash table, copies
+    with 1- and 2-byte offsets, literals of any length.  TensorFlow's tables are written by LevelDB's builder, which
+    Snappy-compresses a block when that saves at least 1/8; write_table(compress=True) does the same with this, so
+    that the reader is exercised on compressed blocks (checkpoint keys such as conv2d_12/kernel/Adam_1 repeat a lot)."""
+    data = bytes(data)
+    n = len(data)
+    out = bytearray(_put_varint(n))
+
+    def literal(lo, hi):
+        while lo < hi:
+            ln = min(hi - lo, 1 << 16)
+            if ln <= 60:
+                out.append((ln - 1) << 2)
+            else:
+                nb = 1 if ln - 1 < 256 else 2
+                out.append((59 + nb) << 2)
+                out.extend((ln - 1).to_bytes(nb, 'little'))
+            out.extend(data[lo:lo + ln])
+            lo += ln
+
+    table, i, lit = {}, 0, 0
+    while i + 4 <= n:
+        key = data[i:i + 4]
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand < 65536:
+            m = 4
+            while i + m < n and m < 64 and data[cand + m] == data[i + m]:
+                m += 1
+            literal(lit, i)
+            off = i - cand
+            if m <= 11 and off < 2048:
+                out.append(((m - 4) << 2) | 1 | ((off >> 8) << 5))
+                out.append(off & 0xFF)
+            else:
+                out.append(((m - 1) << 2) | 2)
+                out.extend(off.to_bytes(2, 'little'))
+            i += m
+            lit = i
+        else:
+            i += 1
+    literal(lit, n)
+    return bytes(out)
+
+
 # ---- table blocks ------------------------------------------------------------------------------------
 def _read_block(f, offset, size, verify=True):
     f.seek(offset)
@@ -378,13 +424,19 @@ class _BlockBuilder(object):
         return len(self.buf) + 4 * len(self.restarts) + 4
 
 
-def write_table(path, items, block_size=4096):
-    """items: iterable of (key bytes, value bytes) in strictly increasing key order.  Blocks are stored
-    uncompressed (type 0), as TensorFlow does when compression does not pay."""
+def write_table(path, items, block_size=4096, compress=False):
+    """items: iterable of (key bytes, value bytes) in strictly increasing key order.  compress=False: blocks are
+    stored raw (type 0); compress=True: a block is stored Snappy-compressed (type 1) when that saves at least 1/8 of
+    it, as LevelDB's table builder (which writes TensorFlow's .index files) does."""
     with open(path, 'wb') as f:
         def emit(body):
             off = f.tell()
-            trailer = bytes([0])
+            ctype = 0
+            if compress:
+                packed = snappy_compress(body)
+                if len(packed) < len(body) - len(body) // 8:
+                    body, ctype = packed, 1
+            trailer = bytes([ctype])
             f.write(body + trailer + struct.pack('<I', mask_crc(crc32c(body + trailer))))
             return off, len(body)
 
@@ -494,29 +546,37 @@ def load_checkpoint(prefix, verify=True, names=None):
     return out
 
 
-def save_checkpoint(prefix, tensors):
-    """Writes {name: array-like} as a one-shard V2 checkpoint that `tf.train.Saver.restore` /
-    `tf.train.load_checkpoint` read: `<prefix>.index`, `<prefix>.data-00000-of-00001`."""
+def save_checkpoint(prefix, tensors, num_shards=1, compress_index=False):
+    """Writes {name: array-like} as a V2 checkpoint that `tf.train.Saver.restore` / `tf.train.load_checkpoint` read:
+    `<prefix>.index` and `<prefix>.data-0000k-of-0000n`.  The Saver of a single-device graph writes one shard
+    (num_shards=1, the default); a sharded Saver spreads the tensors over several data files -- num_shards > 1 deals
+    them out round-robin (each BundleEntryProto names its shard_id).  compress_index: see write_table."""
     d = os.path.dirname(prefix)
     if d:
         os.makedirs(d, exist_ok=True)
     items = []
-    offset = 0
-    with open(_data_path(prefix, 0, 1), 'wb') as f:
-        for name in sorted(tensors, key=lambda s: s.encode()):
+    files = [open(_data_path(prefix, s, num_shards), 'wb') for s in range(num_shards)]
+    offsets = [0] * num_shards
+    try:
+        for j, name in enumerate(sorted(tensors, key=lambda s: s.encode())):
             a = np.asarray(tensors[name])           # (np.ascontiguousarray would turn a 0-d array into 1-d)
             if a.dtype not in _DTYPE_OF:
                 raise ValueError('%s: dtype %s has no TensorFlow counterpart here' % (name, a.dtype))
             raw = a.tobytes()
-            f.write(raw)
+            shard = j % num_shards
+            files[shard].write(raw)
             entry = (_pb_varint_field(1, _DTYPE_OF[a.dtype]) + _pb_bytes_field(2, _encode_shape(a.shape)) +
-                     (_pb_varint_field(4, offset) if offset else b'') + _pb_varint_field(5, len(raw)) +
+                     (_pb_varint_field(3, shard) if shard else b'') +
+                     (_pb_varint_field(4, offsets[shard]) if offsets[shard] else b'') + _pb_varint_field(5, len(raw)) +
                      _pb_fixed32_field(6, mask_crc(crc32c_array(a))))
             items.append((name.encode(), entry))
-            offset += len(raw)
-    # BundleHeaderProto { num_shards = 1; endianness = LITTLE (0, default: omitted); version { producer = 1 } }
-    header = _pb_varint_field(1, 1) + _pb_bytes_field(3, _pb_varint_field(1, 1))
-    write_table(prefix + '.index', [(b'', header)] + items)
+            offsets[shard] += len(raw)
+    finally:
+        for f in files:
+            f.close()
+    # BundleHeaderProto { num_shards; endianness = LITTLE (0, default: omitted); version { producer = 1 } }
+    header = _pb_varint_field(1, num_shards) + _pb_bytes_field(3, _pb_varint_field(1, 1))
+    write_table(prefix + '.index', [(b'', header)] + items, compress=compress_index)
 
 
 def update_checkpoint_state(prefix):

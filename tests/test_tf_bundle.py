@@ -161,3 +161,84 @@ def test_model_level_save_restore_with_tf_names(tmp_path):
     with pytest.raises(KeyError):
         c = engine.ConvStack([engine.LayerSpec(3, 3, 8, scope='other')], device='cpu')
         c.load_tf_checkpoint(prefix)
+
+
+def test_snappy_compressor_round_trips_and_uses_every_element_kind():
+    """snappy_compress -> snappy_decompress on inputs that force literals of every length class, 1- and 2-byte-offset
+    copies and overlapping copies (a run of one byte is a copy of offset 1 onto its own output)."""
+    rng = np.random.default_rng(0)
+    cases = [b'', b'a', b'abcd' * 3, b'x' * 1000, bytes(rng.integers(0, 256, 5000, dtype=np.uint8)),
+             bytes(rng.integers(0, 256, 200, dtype=np.uint8)),
+             b''.join(b'conv2d_%d/kernel/Adam_1' % i for i in range(40)),
+             bytes(rng.integers(0, 4, 70000, dtype=np.uint8)),                       # offsets beyond 2048, long matches
+             bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 20]
+    kinds = set()
+    for data in cases:
+        packed = tb.snappy_compress(data)
+        assert tb.snappy_decompress(packed) == data
+        pos = len(tb._put_varint(len(data)))
+        while pos < len(packed):                       # walk the element stream: which tags occur?
+            tag = packed[pos]
+            kind = tag & 3
+            if kind == 0:
+                ln = tag >> 2
+                extra = ln - 59 if ln >= 60 else 0
+                ln = (int.from_bytes(packed[pos + 1:pos + 1 + extra], 'little') if extra else ln) + 1
+                kinds.add('literal%d' % extra)
+                pos += 1 + extra + ln
+            else:
+                kinds.add('copy%d' % kind)
+                pos += 2 if kind == 1 else 3
+    assert {'literal0', 'literal1', 'literal2', 'copy1', 'copy2'} <= kinds
+    assert len(tb.snappy_compress(b'x' * 1000)) < 60
+
+
+def test_multi_shard_bundle_with_compressed_index(tmp_path):
+    """What a sharded tf.train.Saver writes: tensors spread over several data files (BundleEntryProto.shard_id), and a
+    Snappy-compressed .index (LevelDB's table builder compresses blocks that shrink by 1/8 or more)."""
+    rng = np.random.default_rng(3)
+    tensors = {}
+    for i in range(20):
+        scope = 'conv2d' if i == 0 else 'conv2d_%d' % i
+        tensors[scope + '/kernel'] = rng.normal(size=(3, 3, 4, 8)).astype(np.float32)
+        tensors[scope + '/bias'] = rng.normal(size=(8,)).astype(np.float32)
+        tensors[scope + '/kernel/Adam'] = rng.normal(size=(3, 3, 4, 8)).astype(np.float32)
+        tensors[scope + '/kernel/Adam_1'] = rng.normal(size=(3, 3, 4, 8)).astype(np.float32)
+    tensors['global_step'] = np.asarray(7, np.int64)
+    prefix = str(tmp_path / 'model.ckpt-7')
+    tb.save_checkpoint(prefix, tensors, num_shards=3, compress_index=True)
+    assert sorted(os.listdir(str(tmp_path))) == ['model.ckpt-7.data-00000-of-00003', 'model.ckpt-7.data-00001-of-00003',
+                                                 'model.ckpt-7.data-00002-of-00003', 'model.ckpt-7.index']
+    # the index really holds compressed blocks (type byte 1 after a block body) and is smaller than the raw one
+    tb.save_checkpoint(str(tmp_path / 'raw' / 'model.ckpt-7'), tensors, num_shards=3)
+    assert os.path.getsize(prefix + '.index') < 0.8 * os.path.getsize(str(tmp_path / 'raw' / 'model.ckpt-7.index'))
+    got = tb.load_checkpoint(prefix)
+    assert set(got) == set(tensors)
+    for k in tensors:
+        assert np.array_equal(got[k], tensors[k]) and got[k].dtype == np.asarray(tensors[k]).dtype
+    table = tb.read_table(prefix + '.index')
+    assert dict((f, v) for f, _, v in tb._pb_fields(table[b'']))[1] == 3
+    assert {tb._decode_entry(v)['shard_id'] for k, v in table.items() if k} == {0, 1, 2}
+    # a missing shard is an error, not silent zeros
+    os.remove(prefix + '.data-00001-of-00003')
+    with pytest.raises(OSError):
+        tb.load_checkpoint(prefix)
+
+
+def test_unsupported_bundle_features_are_refused_loudly(tmp_path):
+    """Big-endian bundles and partitioned (sliced) variables -- neither can come from the reference's single-device
+    graphs -- raise instead of returning wrong data."""
+    prefix = str(tmp_path / 'be')
+    entry = (tb._pb_varint_field(1, 1) + tb._pb_bytes_field(2, tb._encode_shape((2,))) + tb._pb_varint_field(5, 8) +
+             tb._pb_fixed32_field(6, 0))
+    header_be = tb._pb_varint_field(1, 1) + tb._pb_varint_field(2, 1)
+    tb.write_table(prefix + '.index', [(b'', header_be), (b'v', entry)])
+    open(prefix + '.data-00000-of-00001', 'wb').write(b'\\0' * 8)
+    with pytest.raises(ValueError, match='big-endian'):
+        tb.load_checkpoint(prefix)
+    prefix = str(tmp_path / 'sliced')
+    sliced = entry + tb._pb_bytes_field(7, b'')
+    tb.write_table(prefix + '.index', [(b'', tb._pb_varint_field(1, 1)), (b'v', sliced)])
+    open(prefix + '.data-00000-of-00001', 'wb').write(b'\\0' * 8)
+    with pytest.raises(ValueError, match='partitioned'):
+        tb.load_checkpoint(prefix)
