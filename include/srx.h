@@ -255,6 +255,13 @@ int srx_gaussian_blur(const float* in, float* out, float* tmp, int N, int H, int
 int srx_resize_bilinear(const float* in, float* out, int N, int H, int W, int C, int OH, int OW,
                         srx_stream_t stream);
 
+/* tf.image.resize_bicubic(images, [OH, OW]) with TensorFlow 1.x semantics (align_corners=False, no half-pixel centres:
+ * in = out * IN / OUT; cubic kernel A = -0.75 evaluated on TF's 1024-step grid; taps clamped to the image): SRCNN's
+ * in-graph degradation, srcnn/srcnn.py:89-93.  [N,H,W,C] -> [N,OH,OW,C].  An integer down-scaling factor is plain
+ * decimation (weights 0,1,0,0).  Pinned against the reference's assets/srcnn_00{0,1}.jpg panels. */
+int srx_resize_bicubic_tf(const float* in, float* out, int N, int H, int W, int C, int OH, int OW,
+                          srx_stream_t stream);
+
 /* tf.image.resize_nearest_neighbor by an integer factor (pixel replication):
  * in [N,H,W,C] -> out [N,H*f,W*f,C].  enet/enet/model_enet.py:78-80. */
 int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f,

@@ -27,7 +27,7 @@ EXPORTS = [
     'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
     'srx_conv2d_bwd_data_acc', 'srx_conv3x3_blocked', 'srx_espcn_forward', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_subsample2', 'srx_subsample2_bwd',
     'srx_channel_blocks_to_nhwc', 'srx_nhwc_to_channel_blocks', 'srx_channel_normalize', 'srx_channel_normalize_bwd',
-    'srx_extract_patches16', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
+    'srx_extract_patches16', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_resize_bicubic_tf', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
 ]
 
 
@@ -115,6 +115,7 @@ def lib():
     L.srx_vgg_preprocess.argtypes = [vp, vp, sz, i, vp]
     L.srx_column_sums.argtypes = [vp, vp, i, i, i, vp]
     L.srx_add_scaled.argtypes = [vp, vp, vp, sz, f, f, vp]
+    L.srx_resize_bicubic_tf.argtypes = [vp, vp, i, i, i, i, i, i, vp]
     L.srx_gemm_workspace_bytes.argtypes = [i, i, i, i]
     L.srx_gemm_workspace_bytes.restype = sz
     L.srx_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp, vp, vp, vp, vp, sz, vp]

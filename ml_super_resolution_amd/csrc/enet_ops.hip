@@ -235,6 +235,63 @@ __global__ __launch_bounds__(256) void vgg_pre_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tf.image.resize_bicubic(images, [OH, OW]) as TensorFlow 1.x computes it (align_corners=False, no half-pixel
+// centres): SRCNN's in-graph degradation, srcnn/srcnn.py:89-93 (down by the factor, up again).
+//   in = out * (IN / OUT);  lower = floor(in);  offset = lrint((in - lower) * 1024)
+//   weights from the cubic convolution kernel with A = -0.75 evaluated at offset / 1024 (TF's 1024-entry table):
+//     w1 = ((A+2) x - (A+3)) x^2 + 1,  w0 = ((A x' - 5A) x' + 8A) x' - 4A with x' = x + 1,  w2 / w3 the same at 1 - x
+//   taps lower-1 .. lower+2, clamped to the image; rows are interpolated along x first, then along y.
+// An integer down-scaling factor gives offset 0 everywhere: weights (0,1,0,0) = plain decimation, no anti-aliasing.
+// Pinned by the reference's own outputs: assets/srcnn_00{0,1}.jpg show hd | sd | sr panels, and this restatement
+// reproduces their sd panel from their hd panel to JPEG noise (41-42.5 dB; A = -0.5: 1.6 dB less; half-pixel centres:
+// 20-24 dB) -- tests/test_oracle_pins.py::test_p6_*.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bicubic_tf_taps(int o, float scale, int limit, int (&idx)[4], float (&w)[4]) {
+#pragma clang fp contract(off)
+    const float A = -0.75f;
+    const float in = (float)o * scale;
+    const float fl = floorf(in);
+    const int lower = (int)fl;
+    const int offset = (int)lrintf((in - fl) * 1024.0f);
+    const float x = (float)offset / 1024.0f, xr = (float)(1024 - offset) / 1024.0f;
+    const float x1 = x + 1.0f, xr1 = xr + 1.0f;
+    w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    w[0] = ((A * x1 - 5.0f * A) * x1 + 8.0f * A) * x1 - 4.0f * A;
+    w[2] = ((A + 2.0f) * xr - (A + 3.0f)) * xr * xr + 1.0f;
+    w[3] = ((A * xr1 - 5.0f * A) * xr1 + 8.0f * A) * xr1 - 4.0f * A;
+    for (int k = 0; k < 4; ++k) {
+        int i = lower - 1 + k;
+        idx[k] = i < 0 ? 0 : (i > limit - 1 ? limit - 1 : i);
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_bicubic_tf_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H,
+                                                                int W, int C, int OH, int OW, float sy, float sx) {
+    const size_t total = (size_t)N * OH * OW * C;
+    SRX_GRID_STRIDE(i, total) {
+#pragma clang fp contract(off)
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int n = (int)(p / OH);
+        int iy[4], ix[4];
+        float wy[4], wx[4];
+        bicubic_tf_taps(oy, sy, H, iy, wy);
+        bicubic_tf_taps(ox, sx, W, ix, wx);
+        const float* img = in + (size_t)n * H * W * C + c;
+        float acc = 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const float* row = img + (size_t)iy[r] * W * C;
+            float v = 0.f;
+            for (int k = 0; k < 4; ++k) v += wx[k] * row[(size_t)ix[k] * C];
+            acc += wy[r] * v;
+        }
+        out[i] = acc;
+    }
+}
+
 // out = alpha * a + beta * b  (gradients that reach one tensor from two consumers; loss-weight scaling)
 __global__ __launch_bounds__(256) void add_scaled_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                          size_t n, float alpha, float beta) {
@@ -526,6 +583,15 @@ int srx_vgg_preprocess(const float* in, float* out, size_t pixels, int backward,
     if (pixels == 0) return SRX_OK;
     hipLaunchKernelGGL(vgg_pre_kernel, dim3(ew_blocks(pixels * 3)), dim3(256), 0, (hipStream_t)stream, in, out, pixels, backward);
     SRX_LAUNCHED("vgg_preprocess");
+}
+
+int srx_resize_bicubic_tf(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, srx_stream_t stream) {
+    if (!in || !out) return set_error(SRX_ERR_BAD_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return set_error(SRX_ERR_BAD_ARG, "bad resize dims");
+    if (in == out) return set_error(SRX_ERR_BAD_ARG, "resize cannot run in place");
+    hipLaunchKernelGGL(resize_bicubic_tf_kernel, dim3(ew_blocks((size_t)N * OH * OW * C)), dim3(256), 0, (hipStream_t)stream, in, out, N, H,
+                       W, C, OH, OW, (float)H / (float)OH, (float)W / (float)OW);
+    SRX_LAUNCHED("resize_bicubic_tf");
 }
 
 int srx_add_scaled(const float* a, const float* b, float* out, size_t n, float alpha, float beta, srx_stream_t stream) {

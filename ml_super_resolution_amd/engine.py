@@ -84,6 +84,9 @@ class ConvStack(object):
         self.overlap_wgrad = os.environ.get('SRX_OVERLAP_WGRAD', '0') != '0'   # wgrads on a side stream (see loss_and_backward; measured 1 % slower: off)
         self.overlap_reduce = os.environ.get('SRX_OVERLAP_REDUCE', '0') != '0'  # partial-filter reductions on a side stream (see loss_and_backward)
         self._ws2 = None
+        # variable leaf names: tf.layers.conv2d creates <scope>/kernel, <scope>/bias; tf.contrib.layers.convolution2d
+        # (SRCNN, srcnn/srcnn.py:100-130) creates <scope>/weights, <scope>/biases
+        self.kernel_name, self.bias_name = 'kernel', 'bias'
 
     # ---- parameter views -------------------------------------------------------------------
     def kernel(self, i, buf=None):
@@ -99,8 +102,8 @@ class ConvStack(object):
         out = {}
         for i, s in enumerate(self.specs):
             scope = s.scope or ('layer%d' % i)
-            out[scope + '/kernel'] = self.kernel(i)
-            out[scope + '/bias'] = self.bias(i)
+            out[scope + '/' + self.kernel_name] = self.kernel(i)
+            out[scope + '/' + self.bias_name] = self.bias(i)
         return out
 
     def load_variables(self, values):
@@ -312,7 +315,7 @@ class ConvStack(object):
             two = self.opt_v is not None
             for i, s in enumerate(self.specs):
                 scope = s.scope or ('layer%d' % i)
-                for kind, view in (('kernel', self.kernel), ('bias', self.bias)):
+                for kind, view in ((self.kernel_name, self.kernel), (self.bias_name, self.bias)):
                     out['%s/%s/%s' % (scope, kind, 'Adam' if two else 'Momentum')] = view(i, self.opt_m).detach().cpu().numpy()
                     if two:
                         out['%s/%s/Adam_1' % (scope, kind)] = view(i, self.opt_v).detach().cpu().numpy()
@@ -350,8 +353,8 @@ class ConvStack(object):
                 buf = torch.zeros_like(self.params)
                 for i, s in enumerate(self.specs):
                     scope = s.scope or ('layer%d' % i)
-                    self.kernel(i, buf).copy_(torch.as_tensor(values['%s/kernel/%s' % (scope, slot)]).to(self.device))
-                    self.bias(i, buf).copy_(torch.as_tensor(values['%s/bias/%s' % (scope, slot)]).to(self.device))
+                    self.kernel(i, buf).copy_(torch.as_tensor(values['%s/%s/%s' % (scope, self.kernel_name, slot)]).to(self.device))
+                    self.bias(i, buf).copy_(torch.as_tensor(values['%s/%s/%s' % (scope, self.bias_name, slot)]).to(self.device))
                 setattr(self, attr, buf)
 
     def load_checkpoint(self, path):

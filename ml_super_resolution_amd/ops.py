@@ -293,6 +293,15 @@ def resize_bilinear(x, oh, ow):
     return out
 
 
+def resize_bicubic_tf(x, oh, ow):
+    """tf.image.resize_bicubic(x, [oh, ow]) with TensorFlow 1.x semantics (srcnn/srcnn.py:89-93)."""
+    _chk(x, 'x')
+    N, H, W, C = x.shape
+    out = torch.empty((N, int(oh), int(ow), C), dtype=torch.float32, device=x.device)
+    check(lib().srx_resize_bicubic_tf(_ptr(x), _ptr(out), N, H, W, C, int(oh), int(ow), _stream()), 'srx_resize_bicubic_tf')
+    return out
+
+
 def upsample_nearest(x, f):
     _chk(x, 'x')
     N, H, W, C = x.shape

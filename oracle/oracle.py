@@ -291,6 +291,38 @@ def resize_bilinear(x, oh, ow):
     return out
 
 
+def resize_bicubic_tf(x, oh, ow, A=-0.75, half_pixel=False):
+    """tf.image.resize_bicubic(x, [oh, ow]) as TensorFlow 1.x computes it (align_corners=False; resize_bicubic_op.cc as
+    remembered, and PINNED by the reference's assets/srcnn_00{0,1}.jpg panels -- pin P6): in = out * IN / OUT (no
+    half-pixel centres), offset = rint(frac * 1024), cubic-convolution weights with A = -0.75 at offset / 1024, taps
+    lower-1..lower+2 clamped to the image.  srcnn/srcnn.py:89-93.  `A` / `half_pixel` exist only so that the pin test
+    can show that the alternatives do NOT reproduce the reference's panels."""
+    x = np.asarray(x, np.float64)
+    K = 1024
+
+    def taps(out_size, in_size):
+        scale = in_size / out_size
+        idx = np.zeros((out_size, 4), np.int64)
+        w = np.zeros((out_size, 4))
+        for o in range(out_size):
+            loc = (o + 0.5) * scale - 0.5 if half_pixel else o * scale
+            fl = int(np.floor(loc))
+            off = int(np.rint((loc - fl) * K))
+            xs = np.array([off / K + 1.0, off / K, (K - off) / K, (K - off) / K + 1.0])
+            w[o, 1] = ((A + 2) * xs[1] - (A + 3)) * xs[1] ** 2 + 1
+            w[o, 2] = ((A + 2) * xs[2] - (A + 3)) * xs[2] ** 2 + 1
+            w[o, 0] = ((A * xs[0] - 5 * A) * xs[0] + 8 * A) * xs[0] - 4 * A
+            w[o, 3] = ((A * xs[3] - 5 * A) * xs[3] + 8 * A) * xs[3] - 4 * A
+            idx[o] = np.clip([fl - 1, fl, fl + 1, fl + 2], 0, in_size - 1)
+        return idx, w
+
+    N, H, W, C = x.shape
+    iy, wy = taps(oh, H)
+    ix, wx = taps(ow, W)
+    rows = sum(x[:, :, ix[:, k], :] * wx[:, k][None, None, :, None] for k in range(4))      # along x first
+    return sum(rows[:, iy[:, k]] * wy[:, k][None, :, None, None] for k in range(4))
+
+
 def hd_to_sd(hd01, scaling_factor):
     """vdsr/vdsr/dataset.py:13-38 on a batch of float images in [0,1]."""
     N, H, W, C = hd01.shape

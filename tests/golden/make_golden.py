@@ -75,6 +75,21 @@ def make_pins():
         crops[name.replace('.', '_')] = arr[80:176, 80:176].copy()
     np.savez_compressed(os.path.join(HERE, 'pin_p3_crop.npz'), **crops)
     make_pin_p5()
+    make_pin_p6()
+
+
+def make_pin_p6():
+    """P6: assets/srcnn_000.jpg and srcnn_001.jpg are the panels hd | sd | sr (231x231 each) that srcnn/srcnn.py:169-184,263-278
+    writes: sd = resize_bicubic(resize_bicubic(hd_crop, 81), 243) cropped like hd (:89-93,132-136).  The decoded pixels
+    of the hd and sd panels are data the reference holds about TensorFlow's bicubic resize; the fixture keeps them
+    (both images, uint8)."""
+    from PIL import Image
+    out = {}
+    for j in (0, 1):
+        im = np.asarray(Image.open(os.path.join(ASSETS, 'srcnn_%03d.jpg' % j)).convert('RGB'))
+        out['hd%d' % j] = im[:, :231].copy()
+        out['sd%d' % j] = im[:, 231:462].copy()
+    np.savez_compressed(os.path.join(HERE, 'pin_p6_srcnn_panels.npz'), **out)
 
 
 P5_CROP = (60, 108, 70, 134)     # rows y0:y1, columns x0:x1 of the 224x224 source (eagle's head)

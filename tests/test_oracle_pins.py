@@ -114,3 +114,36 @@ def test_p5_bicubic_bq_png_bytes():
     # (a fused multiply-add would NOT be: it rounds once and moves bytes by one level)
     fused = np.floor(np.clip(x.astype(np.float64) * 127.5 + 127.5, 0, 255)).astype(np.uint8)
     assert (fused != ref).any()
+
+
+def _p6_psnr(hd, sd, **kw):
+    """PSNR (dB, 8-bit scale) between the reference's sd panel and resize_bicubic(resize_bicubic(hd, 77), 231) away from
+    the border (the panel is the centre of a 243-pixel crop: the outermost pixels saw rows / columns we do not have)."""
+    x = hd.astype(np.float64)[None]
+    up = O.resize_bicubic_tf(O.resize_bicubic_tf(x, 77, 77, **kw), 231, 231, **kw)[0]
+    m = 15
+    d = np.clip(up, 0, 255)[m:-m, m:-m] - sd.astype(np.float64)[m:-m, m:-m]
+    return 10 * np.log10(255.0 ** 2 / np.mean(d * d))
+
+
+def test_p6_tf_bicubic_resize_reproduces_the_reference_panels():
+    """assets/srcnn_00{0,1}.jpg = hd | sd | sr panels written by srcnn/srcnn.py:169-184,263-278, sd being TensorFlow's
+    resize_bicubic down by 3 and up again (:89-93).  The restatement (no half-pixel centres, A = -0.75, TF's 1024-step
+    weight table, so an integer down-scale is plain decimation) reproduces the reference's sd from the reference's hd
+    to JPEG noise, and the alternatives one might have restated instead do clearly worse -- a statistical pin (the
+    panels are JPEGs), but one held by the reference itself."""
+    z = np.load(os.path.join(GOLDEN, 'pin_p6_srcnn_panels.npz'))
+    for j in (0, 1):
+        hd, sd = z['hd%d' % j], z['sd%d' % j]
+        assert hd.shape == sd.shape == (231, 231, 3)
+        ours = _p6_psnr(hd, sd)
+        keys = _p6_psnr(hd, sd, A=-0.5)                           # the other common cubic coefficient
+        half = _p6_psnr(hd, sd, A=-0.5, half_pixel=True)          # "modern" bicubic (half-pixel centres, Keys)
+        assert ours > 40.0, ours                                   # measured 42.5 / 40.9 dB
+        assert ours > keys + 1.0 and ours > half + 15.0, (ours, keys, half)
+    # an integer down-scaling factor is plain decimation: weights (0, 1, 0, 0)
+    x = np.random.default_rng(0).uniform(-1, 1, (1, 12, 9, 2))
+    np.testing.assert_array_equal(O.resize_bicubic_tf(x, 4, 3), x[:, ::3, ::3])
+    # identity at scale 1; constants stay constant (the four weights sum to one at every table offset)
+    np.testing.assert_allclose(O.resize_bicubic_tf(x, 12, 9), x, atol=1e-15)
+    np.testing.assert_allclose(O.resize_bicubic_tf(np.full((1, 5, 7, 1), 3.25), 13, 11), 3.25, atol=1e-12)
