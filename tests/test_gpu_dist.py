@@ -137,3 +137,30 @@ def test_bench_launches_its_own_ranks():
     assert line['config']['global_batch'] == 512
     assert line['value'] > 0 and line['allreduce_ms'] > 0
     assert line['roofline']['frac'] > 0
+
+
+def test_bench_default_line_has_the_contract_keys():
+    """`python bench.py` (N = 1, as the driver runs it): ONE JSON line with the contract's keys, `roofline` and
+    `cpu_baseline` objects, and the secondary north-star numbers."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode(errors='replace')[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['steps'] == 3 and line['dtype'] == 'f32' and line['vs_baseline'] is None
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert 0.5 < r['frac'] < 1.0 and ('traffic' in r)
+    c = line['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    assert abs(line['value'] - 256 * 1000.0 / line['ms_per_step']) < 0.01 * line['value']
+    for key in ('dgrad', 'wgrad', 'subpixel', 'espcn_c2_us', 'srcnn_c1_us', 'enet_pat', 'fwd_hr_mpix_per_s'):
+        assert key in line, key
+    assert line['subpixel']['bound'] == 'hbm' and 0.3 < line['subpixel']['frac'] < 1.0
+    assert 'error' not in line['enet_pat'], line['enet_pat']
