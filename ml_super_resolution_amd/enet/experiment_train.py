@@ -41,11 +41,14 @@ def parse_flags(argv=None):
     return ap.parse_args(argv)
 
 
-def synthetic_batches(batch_size, device, seed=0):
+def synthetic_batches(batch_size, device, seed=0, hd_size=128):
+    """hd_size: side of the HR patches (the reference trains on 128: experiment_train.py:15-22; BASELINE config 5
+    names 512x512 tiles)."""
     g = torch.Generator(device=device).manual_seed(seed)
+    s = hd_size // 4
     while True:
-        hd = torch.rand((batch_size, 128, 128, 3), device=device, generator=g) * 2 - 1
-        sd = hd.view(batch_size, 32, 4, 32, 4, 3).mean(dim=(2, 4))
+        hd = torch.rand((batch_size, hd_size, hd_size, 3), device=device, generator=g) * 2 - 1
+        sd = hd.view(batch_size, s, 4, s, 4, 3).mean(dim=(2, 4))
         bq = sd.repeat_interleave(4, dim=1).repeat_interleave(4, dim=2)
         yield sd.contiguous(), bq.contiguous(), hd
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-ordered MFMA asm blocks: hipcc pads no hazards across an inline-asm
-boundary, so no VALU instruction may write a VGPR that an asm MFMA block reads within the two
-instructions before the block (VALU write -> MFMA operand needs 2 wait states).  Blocks that start
-with their own s_nop (the GUARD variants) are exempt.
+boundary, so no VALU instruction may write a register -- a VGPR, or an accumulation register through
+v_accvgpr_write / v_accvgpr_mov -- that an asm MFMA block reads within the two instructions before the
+block (VALU write -> MFMA operand needs 2 wait states).  Blocks that start with their own s_nop (the GUARD
+variants) are exempt.
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only X.hip -o X.s && check_asm_hazards.py X.s
 """
@@ -11,12 +12,13 @@ import sys
 
 
 def regs(tok):
+    """Registers named in an operand string, as ('v' | 'a', index) pairs (VGPRs and accumulation registers)."""
     out = set()
-    for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', tok):
+    for m in re.finditer(r'\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b', tok):
         if m.group(1):
-            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            out.update((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
         else:
-            out.add(int(m.group(3)))
+            out.add((m.group(4), int(m.group(5))))
     return out
 
 
