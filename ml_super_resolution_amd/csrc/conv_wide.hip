@@ -309,7 +309,14 @@ __device__ __forceinline__ void wide_commit(float* buf, const f32x4 (&v)[J1 - J0
     for (int j = J0; j < J1; ++j) *reinterpret_cast<f32x4*>(buf + (sp + 16 * j) * kPS + 4 * c4) = v[j - J0];
 }
 
-template <bool WT>
+// MASK (template): the launch has a mask operand.  A compile-time property: a conditional load makes hipcc's wait-count
+// bookkeeping assume the load may be pending, and every later wait then drains the whole queue -- filter loads and
+// output stores included.  For the same reason the bias comes from LDS, and the epilogue below is loads-free.
+// ONE (template): tiles of <= 64 pixels, one group per step; otherwise every step runs two groups (on an edge tile of
+// <= 64 pixels the second one computes on pixel 0 and stores nothing).  Not a run-time branch: where the two forms
+// joined, the compiler kept the next filter slice in different registers on either side and drained the queue to
+// move it.
+template <bool WT, bool MASK, bool ONE>
 __global__ __launch_bounds__(256, 1) void conv_wide_pipe_kernel(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int JH = 9;                                   // passes carried by the first group (the rest by the second)
@@ -352,6 +359,9 @@ __global__ __launch_bounds__(256, 1) void conv_wide_pipe_kernel(const WideArgs a
                                                  live ? 9 * 64 * 64 * 4 : 0, 0x00020000);
     };
 
+    float* lds_bias = lds + 2 * kBufSlots * kPS;             // [PB * 64], behind the two tile buffers
+    for (int i = tid; i < a.PB * 64; i += 256) lds_bias[i] = a.bias ? a.bias[i] : 0.0f;
+    const int chb = (cout0 + 4 * kq) * 4;                    // the lane's four output channels, bytes inside a pixel
     WideStep d;
     decode(s_begin, d);
     float wr[144];
@@ -383,14 +393,41 @@ __global__ __launch_bounds__(256, 1) void conv_wide_pipe_kernel(const WideArgs a
         const float* buf = lds + cur_buf * (kBufSlots * kPS);
         float* nbuf = lds + (cur_buf ^ 1) * (kBufSlots * kPS);
         const int npx = d.th * d.tw;
-        const int n_sub = (npx + 15) >> 4;
         const float inv_w = 1.0f / (float)d.tw;
         if (d.sb == 0) {
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + d.pb * 64 + cout0 + 4 * kq);
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(lds_bias + d.pb * 64 + cout0 + 4 * kq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc0[i] = bias4; acc1[i] = bias4; }
         }
+        // the unit's output pixels: byte offset of (sub-tile m, this lane) inside the image of the produced block, or
+        // the out-of-range offset (sub-tiles past the tile; every step but the unit's last) -- such stores are dropped,
+        // such loads read zero
+        const bool last_sb = d.sb == a.SB - 1;
+        int eo[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) eo[m] = kOobOffset;
+        if (last_sb) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int t = 16 * m + li;
+                const int orow = fdiv_small(t, inv_w, d.tw);
+                const int ocol = t - orow * d.tw;
+                if (t < npx) eo[m] = (((d.h0 + orow) * a.W + d.ox + ocol) * 64) * 4 + chb;
+            }
+        }
+        const size_t unit_base = (size_t)d.pb * blk_elems + (size_t)d.n * a.H * a.W * 64;
+        // the mask operand of the whole unit, fetched before the step's last group (lands during it); straight-line:
+        // on the other steps the offsets are out of range
+        f32x4 mk[MASK ? 8 : 1];
+        auto fetch_mask = [&]() {
+            if constexpr (MASK) {
+                const __amdgpu_buffer_rsrc_t mrs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask) + unit_base, 0, img_bytes, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    mk[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, eo[m], 0, 0));
+            }
+        };
         auto group_addresses = [&](int first, int (&la)[4]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -404,45 +441,35 @@ __global__ __launch_bounds__(256, 1) void conv_wide_pipe_kernel(const WideArgs a
         WideStage sg;
         sg.xrs = xrs; sg.nbuf = nbuf; sg.h_in0 = dn.h0 - 1; sg.w_in0 = dn.ox - 1; sg.H = a.H; sg.W = a.W; sg.RS = a.RS;
         sg.n_need = n_need; sg.sp = sp; sg.c4 = c4; sg.inv_rs = a.inv_rs;
-        if (n_sub > 4) {
+        if constexpr (!ONE) {
             {
                 int la[4];
                 group_addresses(0, la);
                 wide_group_pipe<WT, false, 0>(acc0, la, wr, buf, row_stride, wrs, wvlane, sg);
             }
+            fetch_mask();
             int la[4];
             group_addresses(4, la);
             wide_group_pipe<WT, true, 1>(acc1, la, wr, buf, row_stride, wrs, wvlane, sg);
         } else {
+            fetch_mask();
             int la[4];
             group_addresses(0, la);
             wide_group_pipe<WT, true, 2>(acc0, la, wr, buf, row_stride, wrs, wvlane, sg);
         }
         lds_barrier();                   // the next tile is complete; nobody reads this one any more
         cur_buf ^= 1;
-        if (d.sb == a.SB - 1) {
+        if (last_sb) {
             // MFMA results are read by VALU code next: software covers the result latency
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-            const size_t img_off = (size_t)d.pb * blk_elems + (size_t)d.n * a.H * a.W * 64 + cout0 + 4 * kq;
-            float* yb = a.y + img_off;
-            const float* mb = a.mask ? a.mask + img_off : nullptr;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_base, 0, img_bytes, 0x00020000);
             const float slope = act_slope(a.act), mslope = act_slope(a.mask_act);
-            auto store = [&](int first, const f32x4 (&acc)[4]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int t = 16 * (first + i) + li;
-                    if (t < npx) {
-                        const int orow = fdiv_small(t, inv_w, d.tw);
-                        const int ocol = t - orow * d.tw;
-                        const size_t o = ((size_t)(d.h0 + orow) * a.W + d.ox + ocol) * 64;
-                        f32x4 v = act_apply4(acc[i], a.act, slope);
-                        if (mb) v = act_grad4(v, *reinterpret_cast<const f32x4*>(mb + o), a.mask_act, mslope);
-                        *reinterpret_cast<f32x4*>(yb + o) = v;
-                    }
-                }
-            };
-            store(0, acc0);
-            if (n_sub > 4) store(4, acc1);
+            for (int m = 0; m < 8; ++m) {
+                f32x4 v = act_apply4(m < 4 ? acc0[m & 3] : acc1[m & 3], a.act, slope);
+                if constexpr (MASK) v = act_grad4(v, mk[m], a.mask_act, mslope);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrs, eo[m], 0, 0);
+            }
         }
         d = dn;
     }
@@ -496,10 +523,20 @@ extern "C" int srx_conv3x3_blocked(const float* x, const float* w, const float* 
     hipError_t e;
     // SRX_WIDE_PIPE=0: the unpipelined kernel (A/B)
     static const bool use_pipe = [] { const char* v = getenv("SRX_WIDE_PIPE"); return !(v && v[0] == '0'); }();
-    if (use_pipe && n_need <= kBufSlots) {
-        const size_t lds = (size_t)2 * kBufSlots * kPS * 4;
-        if (transpose_filters) e = launch_with_lds(conv_wide_pipe_kernel<true>, a, grid, lds, (hipStream_t)stream);
-        else e = launch_with_lds(conv_wide_pipe_kernel<false>, a, grid, lds, (hipStream_t)stream);
+    const size_t lds_pipe = ((size_t)2 * kBufSlots * kPS + (size_t)produced_blocks * 64) * 4;
+    if (use_pipe && n_need <= kBufSlots && lds_pipe <= 160 * 1024) {
+        const hipStream_t st = (hipStream_t)stream;
+        const int variant = (transpose_filters ? 4 : 0) | (mask ? 2 : 0) | (th * tw <= 64 ? 1 : 0);
+        switch (variant) {
+            case 0: e = launch_with_lds(conv_wide_pipe_kernel<false, false, false>, a, grid, lds_pipe, st); break;
+            case 1: e = launch_with_lds(conv_wide_pipe_kernel<false, false, true>, a, grid, lds_pipe, st); break;
+            case 2: e = launch_with_lds(conv_wide_pipe_kernel<false, true, false>, a, grid, lds_pipe, st); break;
+            case 3: e = launch_with_lds(conv_wide_pipe_kernel<false, true, true>, a, grid, lds_pipe, st); break;
+            case 4: e = launch_with_lds(conv_wide_pipe_kernel<true, false, false>, a, grid, lds_pipe, st); break;
+            case 5: e = launch_with_lds(conv_wide_pipe_kernel<true, false, true>, a, grid, lds_pipe, st); break;
+            case 6: e = launch_with_lds(conv_wide_pipe_kernel<true, true, false>, a, grid, lds_pipe, st); break;
+            default: e = launch_with_lds(conv_wide_pipe_kernel<true, true, true>, a, grid, lds_pipe, st); break;
+        }
     } else {
         const size_t lds = (size_t)n_need * kPS * 4;
         if (transpose_filters) e = launch_with_lds(conv_wide_kernel<true>, a, grid, lds, (hipStream_t)stream);
