@@ -2,7 +2,7 @@
 """Random-shape parity sweep of the round-2 entry points against NumPy float64 / the oracle (a development tool; the
 committed cases live in tests/): srx_conv3x3_blocked (forward, data gradient, fused mask), srx_espcn_forward,
 srx_gemm, max-pooling, the stride-2 sample map, channel normalisation, patch extraction.
-Usage: fuzz_round2.py [cases] [seed]"""
+Usage: fuzz_round2.py [cases] [seed] [wide|espcn|gemm|small_ops]"""
 import os, sys
 import numpy as np
 import torch
@@ -26,6 +26,11 @@ def case_wide(rng):
     if cin == 64 and cout == 64:
         cout = 128
     n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 150 if rng.random() < 0.3 else 70))
+    if rng.random() < 0.25:        # many units per workgroup: the step pipeline crosses tiles, images and produced blocks
+        n, h, w = int(rng.integers(20, 90)), int(rng.integers(1, 25)), int(rng.integers(1, 25))
+        cin, cout = min(cin, 192), min(cout, 192)
+        if cin == 64 and cout == 64:
+            cin = 128
     act = [None, 'relu', 'lrelu'][rng.integers(3)]
     tag = 'wide N%d %dx%d %d->%d %s' % (n, h, w, cin, cout, act)
     k = rng.normal(0, 1 / np.sqrt(9 * cin), (3, 3, cin, cout)).astype(np.float32)
@@ -115,6 +120,8 @@ if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     kinds = [case_wide, case_espcn, case_gemm, case_small_ops]
+    if len(sys.argv) > 3:          # fuzz_round2.py cases seed wide|espcn|gemm|small_ops: one kind only
+        kinds = [k for k in kinds if k.__name__ == 'case_' + sys.argv[3]]
     nbad = 0
     for it in range(cases):
         fn = kinds[it % len(kinds)]

@@ -393,7 +393,9 @@ def test_generic_kernel_without_aux_operand(n, hw, cin, cout):
 
 @pytest.mark.parametrize('cin,cout,hw,n,act', [(128, 128, 8, 3, 'relu'), (512, 512, 4, 2, 'lrelu'), (256, 128, 33, 1, None),
                                                (128, 256, 64, 1, 'relu'), (192, 64, 7, 2, 'relu'), (64, 192, 16, 2, 'lrelu'),
-                                               (128, 128, 130, 1, 'relu'), (128, 64, 65, 1, 'lrelu')])
+                                               (128, 128, 130, 1, 'relu'), (128, 64, 65, 1, 'lrelu'),
+                                               # several units per workgroup: the step pipeline crosses tiles, images, blocks
+                                               (128, 192, 20, 60, 'relu'), (192, 128, 8, 150, 'lrelu')])
 def test_one_launch_wide_layer_equals_block_pair_launches(cin, cout, hw, n, act):
     """srx_conv3x3_blocked (one launch, the sum over the input blocks in registers) against the block-pair launches of
     the 64-channel kernels (the running sum through memory) and against the oracle: forward and data gradient."""
