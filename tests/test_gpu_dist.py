@@ -164,3 +164,4 @@ def test_bench_default_line_has_the_contract_keys():
         assert key in line, key
     assert line['subpixel']['bound'] == 'hbm' and 0.3 < line['subpixel']['frac'] < 1.0
     assert 'error' not in line['enet_pat'], line['enet_pat']
+    assert line['enet_pat']['tiles_512']['g_trainer_ms'] > 0
