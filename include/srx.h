@@ -299,6 +299,16 @@ int srx_conv3x3_blocked(const float* x, const float* w, const float* bias, const
                         int N, int H, int W, int staged_blocks, int produced_blocks, int act,
                         int transpose_filters, srx_stream_t stream);
 
+/* The filter gradient of such a layer (the discriminator's 128..512-channel layers; tf.gradients of
+ * tf.layers.conv2d, enet/enet/model_enet.py:118-146, 331-346): x [staged_blocks][N,H,W,64] (the layer's input),
+ * dpre [produced_blocks][N,H,W,64] -> dw [CIB][COB][3][3][64][64] (the layout of `w` above), dbias [64 COB] (nullable).
+ * Every (input block, output block) pair is a 64 -> 64 problem: ONE launch over all pairs and one reduction of the
+ * per-workgroup partial filters (deterministic order) where the linear-walk kernel covers the shape (rows of up to
+ * about 120 pixels), otherwise one srx_conv2d_bwd_filter per pair.  Workspace: ..._workspace_bytes, 16-byte aligned. */
+size_t srx_conv3x3_blocked_bwd_filter_workspace_bytes(int N, int H, int W, int staged_blocks, int produced_blocks);
+int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw, float* dbias, int N, int H, int W,
+                                   int staged_blocks, int produced_blocks, void* ws, size_t ws_bytes, srx_stream_t stream);
+
 /* tf.nn.max_pool(ksize 2x2, strides 2x2, padding='SAME') (enet/enet/model_vgg.py:28-36): [N,H,W,C] ->
  * [N,ceil(H/2),ceil(W/2),C], C % 4 == 0.  _bwd = MaxPoolGrad given the forward INPUT x: the gradient of a window goes
  * to its first maximum in scan order. */

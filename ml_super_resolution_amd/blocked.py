@@ -14,7 +14,8 @@ convert to and from TensorFlow's [3, 3, Cin, Cout] for checkpoints and tests.
             -- after the add -- in the last: post_add_relu = ReLU / leaky ReLU);
   dgrad     dx[ib] = sum_ob bwd_data(dpre[ob], w[ib][ob]): srx_conv3x3_blocked with transposed filters, or
             srx_conv2d_bwd_data followed by srx_conv2d_bwd_data_acc per further output block;
-  wgrad     dw[ib][ob] = bwd_filter(x[ib], dpre[ob]), independent calls; dbias from the ib = 0 calls;
+  wgrad     dw[ib][ob] = bwd_filter(x[ib], dpre[ob]): independent 64 -> 64 problems, ONE launch over all pairs + one
+            reduction (srx_conv3x3_blocked_bwd_filter); dbias from the ib = 0 pairs;
   stride 2  (TF pads 0 before / 1 after on an even image, model_enet.py:136-146) = the stride-1 layer sampled at the
             odd positions: srx_subsample2 after the forward, zero stuffing (srx_subsample2_bwd) before the gradients.
 """
@@ -178,6 +179,14 @@ class BlockedConv(object):
     def wgrad(self, x, dpre):
         """Fills self.dw / self.db from the layer input x [CIB, N, H, W, ci] and dpre."""
         dp = self._full_res(dpre)
+        if self._wide_ok(x.shape[3]) and x.is_contiguous() and dp.is_contiguous() and self.dw.is_contiguous():
+            _, n, h, w, _ = x.shape
+            need = ops.conv3x3_blocked_bwd_filter_workspace_bytes(n, h, w, self.cib, self.cob)
+            ws = self._scratch.get('ws')
+            if ws is None or ws.numel() * 4 < need:
+                ws = self._scratch['ws'] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+            ops.conv3x3_blocked_bwd_filter(x, dp, self.dw, self.db, workspace=ws)
+            return
         need = max(ops.bwd_filter_workspace_bytes(x[0].shape, self.w[0, 0].shape, 'same'), 16)
         ws = self._scratch.get('ws')
         if ws is None or ws.numel() * 4 < need:

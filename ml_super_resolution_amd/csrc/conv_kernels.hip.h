@@ -1975,6 +1975,24 @@ template <int KH, int KW, int CINP, int NCH, int MINW>
 __global__ __launch_bounds__(256, MINW) void wgrad_lin_strip_kernel(const WgradArgs a) {
     wgrad_lin_body<KH, KW, CINP, NCH, MINW, true>(a);
 }
+// The filter gradients of a layer wider than 64 channels on channel-blocked tensors: every (input block, output block)
+// pair is an independent 64 -> 64 problem of the same geometry; blockIdx.y picks the pair, the body never looks at it.
+struct WgradPairs {
+    WgradArgs a;                 // the pair (0, 0)
+    long x_pair_stride;          // floats from one input block to the next
+    long d_pair_stride;          // floats from one output block to the next
+    long part_pair_stride;       // floats of partials per pair
+    int cob;                     // output blocks: pair = ib * cob + ob
+};
+template <int KH, int KW, int CINP, int NCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_lin_pairs_kernel(const WgradPairs q) {
+    WgradArgs a = q.a;
+    const int pair = blockIdx.y, ib = pair / q.cob, ob = pair - ib * q.cob;
+    a.x += ib * q.x_pair_stride;
+    a.dpre += ob * q.d_pair_stride;
+    a.part += pair * q.part_pair_stride;
+    wgrad_lin_body<KH, KW, CINP, NCH, MINW, false>(a);
+}
 
 
 // ---------------------------------------------------------------------------------------------

@@ -25,12 +25,16 @@ bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hi
 bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_lin_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_pipe(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_wgrad_lin_pairs(const ConvKey& k, const WgradPairs& q, int grid, int pairs, size_t lds, hipStream_t s, hipError_t* err);
 
 hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
                                   const float* w, float wd, hipStream_t s);
+// `pairs` problems at once: partials [pair][G][stride] -> dw [pair][wn], dbias [cob][cout] (taken from the pairs ib == 0)
+hipError_t launch_reduce_partials_pairs(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
+                                        int pairs, int cob, hipStream_t s);
 
 template <typename K, typename A>
-inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hipStream_t s) {
+inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hipStream_t s, int grid_y = 1) {
     // > 64 KiB of dynamic LDS needs the attribute.  It is raised once per kernel to the largest size the
     // planner can ask for (160 KiB), outside any stream capture of later launches.
     static thread_local const void* configured[64];
@@ -43,7 +47,7 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
         if (e != hipSuccess) return e;
         if (n_configured < 64) configured[n_configured++] = fn;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -533,6 +533,97 @@ int srx_conv2d_bwd_filter(const srx_conv_desc* d, const float* x, const float* d
     return srx_conv2d_bwd_filter_reduce(d, ws, n, dw, dbias, w_for_decay, wd_scale, stream);
 }
 
+// ---- layers wider than 64 channels: the filter gradients of all (input block, output block) pairs -------------------
+namespace {
+void blocked_desc(srx_conv_desc* d, int N, int H, int W) {
+    memset(d, 0, sizeof(*d));
+    d->N = N; d->H = H; d->W = W; d->Cin = 64; d->Cout = 64; d->KH = 3; d->KW = 3; d->stride = 1; d->pad_mode = SRX_PAD_SAME;
+}
+// One launch for all pairs needs the linear-walk kernel (full-width tiles, two workgroups per CU); G partials per pair so
+// that pairs x G fills the chip about once.
+bool pairs_route(const srx_conv_desc* d, const Plan& p, int pairs, int* G, size_t* lin_lds) {
+    *lin_lds = p.lds_bytes + 4 * (size_t)(p.cinp + 4) * 4;
+    const bool lin_ok = knobs().wgrad_lin && p.NTX == 1 && p.cinp == 64 && p.nch == 4 && d->W >= 4 && p.RS >= 8 &&
+                        p.RS == d->W + p.pad_l && (long)p.TH * d->W * 64 * 4 < (1L << 30) &&
+                        (long)d->H * d->W * 64 * 4 < (1L << 31) - 4096 && *lin_lds <= 80 * 1024;
+    int g = max_grid() / pairs;
+    if (g < 1) g = 1;
+    if (g > p.grid) g = p.grid;
+    *G = g;
+    return lin_ok && pairs > 1 && pairs <= 65535;
+}
+}  // namespace
+
+size_t srx_conv3x3_blocked_bwd_filter_workspace_bytes(int N, int H, int W, int staged_blocks, int produced_blocks) {
+    srx_conv_desc d;
+    blocked_desc(&d, N, H, W);
+    if (check_desc(&d) || staged_blocks <= 0 || produced_blocks <= 0) return 0;
+    Plan p;
+    if (make_plan(N, H, W, H, W, 64, 64, 3, 3, 1, 1, &p)) return 0;
+    int G;
+    size_t lin_lds;
+    const int pairs = staged_blocks * produced_blocks;
+    const size_t one = (size_t)p.grid * part_stride(&d) * sizeof(float);
+    if (!pairs_route(&d, p, pairs, &G, &lin_lds)) return one;
+    const size_t all = (size_t)pairs * G * part_stride(&d) * sizeof(float);
+    return all > one ? all : one;
+}
+
+int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw, float* dbias, int N, int H, int W,
+                                   int staged_blocks, int produced_blocks, void* ws, size_t ws_bytes, srx_stream_t stream) {
+    if (!x || !dpre || !dw) return fail(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (staged_blocks <= 0 || produced_blocks <= 0) return fail(SRX_ERR_BAD_ARG, "non-positive block count");
+    srx_conv_desc d;
+    blocked_desc(&d, N, H, W);
+    int rc = check_desc(&d);
+    if (rc) return rc;
+    if (!aligned16(x) || !aligned16(dpre) || !aligned16(dw) || !aligned16(ws))
+        return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
+    const size_t need = srx_conv3x3_blocked_bwd_filter_workspace_bytes(N, H, W, staged_blocks, produced_blocks);
+    if (!ws || ws_bytes < need) return fail(SRX_ERR_WORKSPACE, "blocked bwd_filter needs %zu workspace bytes, got %zu", need, ws_bytes);
+    Plan p;
+    rc = make_plan(N, H, W, H, W, 64, 64, 3, 3, 1, 1, &p);
+    if (rc) return rc;
+    const int pairs = staged_blocks * produced_blocks;
+    const size_t blk = (size_t)N * H * W * 64, wn = (size_t)9 * 64 * 64;
+    int G;
+    size_t lin_lds;
+    if (!pairs_route(&d, p, pairs, &G, &lin_lds)) {
+        // one pair at a time on the single-layer entry point (column strips, odd shapes, a single pair)
+        for (int ib = 0; ib < staged_blocks; ++ib)
+            for (int ob = 0; ob < produced_blocks; ++ob) {
+                rc = srx_conv2d_bwd_filter(&d, x + ib * blk, dpre + ob * blk, dw + ((size_t)ib * produced_blocks + ob) * wn,
+                                           (ib == 0 && dbias) ? dbias + ob * 64 : nullptr, nullptr, 0.f, ws, ws_bytes, stream);
+                if (rc) return rc;
+            }
+        return SRX_OK;
+    }
+    WgradPairs q;
+    memset(&q, 0, sizeof(q));
+    WgradArgs& a = q.a;
+    a.x = x; a.dpre = dpre;
+    a.part = (float*)ws;
+    a.part_stride = (int)part_stride(&d);
+    a.N = N; a.H = H; a.W = W; a.OH = H; a.OW = W; a.Cin = 64; a.Cout = 64;
+    a.pad_t = 1; a.pad_l = 1; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
+    a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
+    a.stagger = 0;
+    a.zero_slot = (p.TH + 2) * p.RS + 2;
+    a.trace = nullptr;
+    q.x_pair_stride = (long)blk; q.d_pair_stride = (long)blk;
+    q.part_pair_stride = (long)G * a.part_stride;
+    q.cob = produced_blocks;
+    ConvKey k{3, 3, 64, 4, false};
+    hipError_t err = hipSuccess;
+    if (!launch_wgrad_lin_pairs(k, q, G, pairs, lin_lds, (hipStream_t)stream, &err))
+        return fail(SRX_ERR_UNSUPPORTED, "no pairs instance of the linear-walk wgrad kernel");
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "blocked wgrad launch failed: %s", hipGetErrorString(err));
+    err = launch_reduce_partials_pairs((const float*)ws, G, a.part_stride, (int)wn, 64, dw, dbias, pairs, produced_blocks,
+                                       (hipStream_t)stream);
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "blocked reduce launch failed: %s", hipGetErrorString(err));
+    return SRX_OK;
+}
+
 #define SRX_CHECK_LAUNCH(expr, what)                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

@@ -5,10 +5,9 @@ namespace srx {
 //   j <  wn : dw[j]      = sum_g part[g][j] (+ wd * w[j])
 //   j >= wn : dbias[j-wn] = sum_g part[g][j]
 // A block owns 64 consecutive outputs; its 256 threads are 16 float4 columns x 16 partial groups.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int G, int stride,
-                                                              int wn, int n, float* __restrict__ dw,
-                                                              float* __restrict__ dbias, const float* __restrict__ w,
-                                                              float wd) {
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int G, int stride, int wn, int n,
+                                                     float* __restrict__ dw, float* __restrict__ dbias,
+                                                     const float* __restrict__ w, float wd) {
     __shared__ f32x4 sh[16][17];
     const int c = threadIdx.x & 15, pg = threadIdx.x >> 4;
     const int j = blockIdx.x * 64 + 4 * c;
@@ -42,6 +41,30 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
                 dbias[jj - wn] = t[e];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int G, int stride,
+                                                              int wn, int n, float* __restrict__ dw,
+                                                              float* __restrict__ dbias, const float* __restrict__ w,
+                                                              float wd) {
+    reduce_partials_body(part, G, stride, wn, n, dw, dbias, w, wd);
+}
+// blockIdx.y = pair (ib * cob + ob) of a layer wider than 64 channels; the bias gradient of output block ob is the one
+// the pair (0, ob) produced (every pair ib, ob sums the same dpre[ob])
+__global__ __launch_bounds__(256) void reduce_partials_pairs_kernel(const float* __restrict__ part, int G, int stride,
+                                                                    int wn, int n, float* __restrict__ dw,
+                                                                    float* __restrict__ dbias, int cob) {
+    const int pair = blockIdx.y;
+    float* db = (dbias && pair < cob) ? dbias + (size_t)pair * (n - wn) : nullptr;
+    reduce_partials_body(part + (size_t)pair * G * stride, G, stride, wn, n, dw + (size_t)pair * wn, db, nullptr, 0.f);
+}
+
+hipError_t launch_reduce_partials_pairs(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,
+                                        int pairs, int cob, hipStream_t s) {
+    const int n = wn + cout;
+    hipLaunchKernelGGL(reduce_partials_pairs_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)pairs), dim3(256), 0, s, part, G,
+                       stride, wn, n, dw, dbias, cob);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, int cout, float* dw, float* dbias,

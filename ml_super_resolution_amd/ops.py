@@ -362,6 +362,27 @@ def conv3x3_blocked(x, w, bias=None, act=None, transpose=False, out=None, mask=N
     return out
 
 
+def conv3x3_blocked_bwd_filter_workspace_bytes(n, h, w, cib, cob):
+    return int(lib().srx_conv3x3_blocked_bwd_filter_workspace_bytes(n, h, w, cib, cob))
+
+
+def conv3x3_blocked_bwd_filter(x, dpre, dw, dbias=None, workspace=None):
+    """Filter gradient of a 3x3 SAME layer wider than 64 channels -- srx_conv3x3_blocked_bwd_filter: all block pairs in
+    one launch + one reduction.  x [CIB, N, H, W, 64], dpre [COB, N, H, W, 64] -> dw [CIB, COB, 3, 3, 64, 64], dbias [64 COB]."""
+    _chk(x, 'x'); _chk(dpre, 'dpre'); _chk(dw, 'dw'); _chk(dbias, 'dbias')
+    cib, n, h, w, c = x.shape
+    cob = dpre.shape[0]
+    if c != 64 or tuple(dpre.shape[1:]) != (n, h, w, 64) or tuple(dw.shape) != (cib, cob, 3, 3, 64, 64) or \
+            (dbias is not None and dbias.numel() != 64 * cob):
+        raise ValueError('conv3x3_blocked_bwd_filter: x %s, dpre %s, dw %s do not fit' % (tuple(x.shape), tuple(dpre.shape), tuple(dw.shape)))
+    need = conv3x3_blocked_bwd_filter_workspace_bytes(n, h, w, cib, cob)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((max(need, 16) + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib().srx_conv3x3_blocked_bwd_filter(_ptr(x), _ptr(dpre), _ptr(dw), _ptr(dbias), n, h, w, cib, cob, _ptr(workspace),
+                                               workspace.numel() * workspace.element_size(), _stream()), 'srx_conv3x3_blocked_bwd_filter')
+    return dw
+
+
 def maxpool2x2(x, out=None):
     """tf.nn.max_pool(ksize 2, strides 2, 'SAME'): [N,H,W,C] -> [N,ceil(H/2),ceil(W/2),C]."""
     _chk(x, 'x')

@@ -21,6 +21,8 @@ STUB_WGRAD(launch_wgrad) STUB_WGRAD(launch_wgrad_lin) STUB_WGRAD(launch_wgrad_li
 bool launch_wgrad_narrow(const ConvKey&, const WgradArgs&, int, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 hipError_t launch_reduce_partials(const float*, int, int, int, int, float*, float*, const float*, float, hipStream_t) { return hipSuccess; }
+hipError_t launch_reduce_partials_pairs(const float*, int, int, int, int, float*, float*, int, int, hipStream_t) { return hipSuccess; }
+bool launch_wgrad_lin_pairs(const ConvKey&, const WgradPairs&, int, int, size_t, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
 hipError_t launch_subpixel(const float*, float*, int, int, int, int, int, bool, hipStream_t) { return hipSuccess; }
 hipError_t launch_mse(const float*, const float*, size_t, float, float*, int, float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_l2(const float*, const float*, size_t, float, float*, int, float*, hipStream_t) { return hipSuccess; }
