@@ -309,6 +309,17 @@ size_t srx_conv3x3_blocked_bwd_filter_workspace_bytes(int N, int H, int W, int s
 int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw, float* dbias, int N, int H, int W,
                                    int staged_blocks, int produced_blocks, void* ws, size_t ws_bytes, srx_stream_t stream);
 
+/* The texture-matching statistics of texture_matching_loss (enet/enet/model_enet.py:225-259) in one pass:
+ *   gram[n*P + p] = patches_p^T patches_p,   patches = extract_image_patches(16x16, stride 16) of normalize(x)
+ *   (normalize: x / (mean over channels + eps), :34-41) -- x [N,H,W,C] -> gram [N*(H/16)*(W/16), C, C].
+ * The same numbers as srx_channel_normalize -> srx_extract_patches16 -> srx_gemm(trans_a) without the two feature-sized
+ * intermediates; exact-fp32 MFMA.  C = 64, 128 or 256 (VGG-19 block1/2/3_conv1), H and W multiples of 16.
+ * _bwd: dx = d loss / d x given dgram = d loss / d gram, SYMMETRIC (the difference of two gram matrices is):
+ *   dn = alpha * n dgram (alpha = 2), pushed through the patch permutation and the gradient of normalize. */
+int srx_texture_gram(const float* x, float* gram, int N, int H, int W, int C, float eps, srx_stream_t stream);
+int srx_texture_gram_bwd(const float* x, const float* dgram, float* dx, int N, int H, int W, int C, float eps, float alpha,
+                         srx_stream_t stream);
+
 /* tf.nn.max_pool(ksize 2x2, strides 2x2, padding='SAME') (enet/enet/model_vgg.py:28-36): [N,H,W,C] ->
  * [N,ceil(H/2),ceil(W/2),C], C % 4 == 0.  _bwd = MaxPoolGrad given the forward INPUT x: the gradient of a window goes
  * to its first maximum in scan order. */

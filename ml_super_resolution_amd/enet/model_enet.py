@@ -22,6 +22,8 @@ Losses (:165-261, row N4): log-loss GAN terms, perceptual MSE on normalised bloc
 `build_enet(sd_images, bq_images, hd_images, pat_model, vgg19_path)` keeps the reference's keys:
   {sd_images, bq_images, sr_images} (+ hd_images, a_loss, g_loss, t_loss, p_loss, g_loss_all, g_trainer, d_trainer, step).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -304,6 +306,11 @@ def perceptual_loss(sr_feats, hd_feats, loss_out, want_grad=True):
     return dt
 
 
+# SRX_TEXTURE_FUSED=0: normalise, patch extraction and gram GEMM as separate launches (A/B; also the route of any
+# channel count the fused kernel has no instance for)
+FUSED_TEXTURE = os.environ.get('SRX_TEXTURE_FUSED', '1') != '0'
+
+
 def texture_matching_loss(sr_feats, hd_feats, loss_out, want_grad=True):
     """loss_out = sum_l w_l * MSE(gram(sr_l), gram(hd_l)), gram = x^T x over each 16x16 patch of the normalised
     features ([N, h*w/256, 256, C] -> [N, h*w/256, C, C]); returns {layer: d loss / d sr feature (NHWC)}."""
@@ -311,6 +318,14 @@ def texture_matching_loss(sr_feats, hd_feats, loss_out, want_grad=True):
     for j, (name, wgt) in enumerate(TEXTURE_LAYERS):
         s, h = model_vgg.Vgg19.tap(sr_feats, name), model_vgg.Vgg19.tap(hd_feats, name)
         n, hh, ww, c = s.shape
+        if FUSED_TEXTURE and c in (64, 128, 256):
+            # normalise + patches + gram in one pass over the feature tensor (srx_texture_gram), and its gradient
+            s, h = s.contiguous(), h.contiguous()
+            gs, gh = ops.texture_gram(s), ops.texture_gram(h)
+            dg = ops.mse_fwd_bwd(gs, gh, loss_out, inv_numel=wgt / gs.numel(), accumulate=j > 0, want_grad=want_grad)
+            if want_grad:
+                dt[name] = ops.texture_gram_bwd(s, dg)
+            continue
         sp = ops.extract_patches16(ops.channel_normalize(s)).view(-1, 256, c)
         hp = ops.extract_patches16(ops.channel_normalize(h)).view(-1, 256, c)
         gs = ops.gemm(sp, sp, trans_a=True)                                 # [N*P, C, C]

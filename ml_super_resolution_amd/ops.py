@@ -383,6 +383,26 @@ def conv3x3_blocked_bwd_filter(x, dpre, dw, dbias=None, workspace=None):
     return dw
 
 
+def texture_gram(x, eps=1e-6, out=None):
+    """Gram matrices of the 16x16 patches of normalize(x) -- srx_texture_gram: [N,H,W,C] -> [N*(H/16)*(W/16), C, C]."""
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    out = out if out is not None else torch.empty((n * (h // 16) * (w // 16), c, c), dtype=torch.float32, device=x.device)
+    check(lib().srx_texture_gram(_ptr(x), _ptr(out), n, h, w, c, eps, _stream()), 'srx_texture_gram')
+    return out
+
+
+def texture_gram_bwd(x, dgram, eps=1e-6, alpha=2.0, out=None):
+    """d loss / d x of texture_gram given the (symmetric) d loss / d gram -- srx_texture_gram_bwd."""
+    _chk(x, 'x'); _chk(dgram, 'dgram')
+    n, h, w, c = x.shape
+    if tuple(dgram.shape) != (n * (h // 16) * (w // 16), c, c):
+        raise ValueError('texture_gram_bwd: dgram %s does not fit x %s' % (tuple(dgram.shape), tuple(x.shape)))
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().srx_texture_gram_bwd(_ptr(x), _ptr(dgram), _ptr(out), n, h, w, c, eps, alpha, _stream()), 'srx_texture_gram_bwd')
+    return out
+
+
 def maxpool2x2(x, out=None):
     """tf.nn.max_pool(ksize 2, strides 2, 'SAME'): [N,H,W,C] -> [N,ceil(H/2),ceil(W/2),C]."""
     _chk(x, 'x')
