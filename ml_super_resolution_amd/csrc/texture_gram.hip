@@ -8,7 +8,8 @@
 // products on exact-fp32 MFMA out of LDS.  Bound: HBM (the feature tensor is read once per 64 gram rows).
 //
 // Forward: workgroup = (patch, block of 64 gram rows); wave = 16 rows x all C columns (C/16 accumulators); K = the
-// patch's 256 pixels, 4 per MFMA, staged 256 (C <= 128) or 128 (C = 256) pixels at a time.
+// patch's 256 pixels, 4 per MFMA, staged 128 (C <= 128) or 64 (C = 256) pixels at a time (<= 74 KB of LDS: two to four
+// workgroups per CU, one filling while another multiplies).
 // Backward (dgram symmetric, as the difference of two gram matrices is): dn = alpha * n . dgram  (alpha = 2:
 // d(n^T n) -> n (dG + dG^T)), then the gradient of normalize: with m = mean + eps, t = sum_c dn_c x_c:
 // dx_c = dn_c / m - t / (C m^2).  Workgroup = (patch, 64 of its pixels); wave = 16 pixels x all C channels; K = the C
@@ -65,7 +66,7 @@ template <int C>
 __global__ __launch_bounds__(256) void texture_gram_kernel(const float* __restrict__ x, float* __restrict__ gram, int H, int W,
                                                            float eps) {
     constexpr int LS = C + 16;                       // (+16: the four pixel rows of a k-step fall on two bank halves)
-    constexpr int KP = (C <= 128) ? 256 : 128;
+    constexpr int KP = (C <= 128) ? 128 : 64;        // pixels per LDS pass: <= 74 KB, two to four workgroups per CU
     constexpr int RB = C / 64, NJ = C / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -80,11 +81,22 @@ __global__ __launch_bounds__(256) void texture_gram_kernel(const float* __restri
         __syncthreads();
         const float* arow = lds + kq * LS + rb * 64 + 16 * wave + li;
         const float* brow = lds + kq * LS + li;
+        // operands of k-step s + 1 are read while the MFMAs of k-step s run
+        float an = arow[0], bn[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bn[j] = brow[16 * j];
 #pragma unroll 2
         for (int s = 0; s < KP / 4; ++s) {
-            const float a = arow[4 * s * LS];
+            const float a = an;
+            float b[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[4 * s * LS + 16 * j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+            const int s1 = (s + 1 < KP / 4) ? s + 1 : s;
+            an = arow[4 * s1 * LS];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bn[j] = brow[4 * s1 * LS + 16 * j];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
         }
     }
     float* g = gram + (size_t)p * C * C + (size_t)(rb * 64 + 16 * wave + 4 * kq) * C + li;
@@ -122,11 +134,21 @@ __global__ __launch_bounds__(256) void texture_gram_bwd_kernel(const float* __re
         __syncthreads();
         const float* arow = tn + (16 * wave + li) * LSN + 64 * jc + kq;
         const float* brow = tg + kq * LSG + li;
+        float an = arow[0], bn[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bn[j] = brow[16 * j];
 #pragma unroll 2
         for (int s = 0; s < 16; ++s) {
-            const float a = arow[4 * s];
+            const float a = an;
+            float b[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[4 * s * LSG + 16 * j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+            const int s1 = (s + 1 < 16) ? s + 1 : s;
+            an = arow[4 * s1];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bn[j] = brow[4 * s1 * LSG + 16 * j];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
         }
     }
     // the lane holds dn[pixel 16 wave + 4 kq + r][channel 16 j + li] / alpha
@@ -184,9 +206,9 @@ extern "C" int srx_texture_gram(const float* x, float* gram, int N, int H, int W
     const int rc = check_dims(x, gram, gram, N, H, W, C);
     if (rc) return rc;
     const long patches = (long)N * (H / 16) * (W / 16);
-    if (C == 64) SRX_TG_LAUNCH(texture_gram_kernel<64>, patches, (size_t)256 * 80 * 4, x, gram, H, W, eps);
-    else if (C == 128) SRX_TG_LAUNCH(texture_gram_kernel<128>, patches * 2, (size_t)256 * 144 * 4, x, gram, H, W, eps);
-    else SRX_TG_LAUNCH(texture_gram_kernel<256>, patches * 4, (size_t)128 * 272 * 4, x, gram, H, W, eps);
+    if (C == 64) SRX_TG_LAUNCH(texture_gram_kernel<64>, patches, (size_t)128 * 80 * 4, x, gram, H, W, eps);
+    else if (C == 128) SRX_TG_LAUNCH(texture_gram_kernel<128>, patches * 2, (size_t)128 * 144 * 4, x, gram, H, W, eps);
+    else SRX_TG_LAUNCH(texture_gram_kernel<256>, patches * 4, (size_t)64 * 272 * 4, x, gram, H, W, eps);
     return SRX_OK;
 }
 
