@@ -272,9 +272,7 @@ class Discriminator(object):
             if masked:
                 dpre = g
             else:
-                dpre = torch.empty_like(g)
-                for b in range(g.shape[0]):
-                    ops.act_bwd(g[b], y[b], 'lrelu', out=dpre[b])
+                dpre = ops.act_bwd(g.contiguous(), y, 'lrelu', out=torch.empty_like(y))
             if want_dw:
                 c.wgrad(acts[i], dpre)
             if i == 0 and not want_dx:

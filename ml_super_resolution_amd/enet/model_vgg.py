@@ -91,9 +91,9 @@ class Vgg19(object):
         for name in LAYER_NAMES:
             if name.endswith('pool'):
                 cb, n, h, w, c = t.shape
+                # (the blocks of a channel-blocked tensor are contiguous: one launch with the blocks as extra images)
                 p = torch.empty((cb, n, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=t.device)
-                for b in range(cb):
-                    ops.maxpool2x2(t[b], out=p[b])
+                ops.maxpool2x2(t.view(cb * n, h, w, c), out=p.view(cb * n, (h + 1) // 2, (w + 1) // 2, c))
                 t = p
             else:
                 t = self.layers[name].forward(t)
@@ -113,10 +113,7 @@ class Vgg19(object):
         if feats is None:
             raise RuntimeError('backward() needs a forward(..., keep=True) first')
         def relu_grad(t, y):                                               # ReluGrad on the post-ReLU tensor
-            out = torch.empty_like(t)
-            for b in range(t.shape[0]):
-                ops.act_bwd(t[b], y[b], 'relu', out=out[b])
-            return out
+            return ops.act_bwd(t.contiguous(), y, 'relu', out=torch.empty_like(y))
 
         g, masked = None, False        # masked: g is already multiplied by ReluGrad of the layer it belongs to
         for idx in range(len(LAYER_NAMES) - 1, -1, -1):
@@ -132,8 +129,9 @@ class Vgg19(object):
             below = feats[below_name]
             if name.endswith('pool'):
                 dx = torch.empty_like(below)
-                for b in range(below.shape[0]):
-                    ops.maxpool2x2_bwd(below[b], g[b], out=dx[b])
+                cb, n, h, w, c = below.shape
+                g = g.contiguous()
+                ops.maxpool2x2_bwd(below.view(cb * n, h, w, c), g.view(cb * n, g.shape[2], g.shape[3], c), out=dx.view(cb * n, h, w, c))
                 g, masked = dx, False
             else:
                 dpre = g if masked else relu_grad(g, feats[name])
