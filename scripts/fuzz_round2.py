@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Random-shape parity sweep of the round-2 entry points against NumPy float64 / the oracle (a development tool; the
 committed cases live in tests/): srx_conv3x3_blocked (forward, data gradient, fused mask), srx_espcn_forward,
-srx_gemm, max-pooling, the stride-2 sample map, channel normalisation, patch extraction.
-Usage: fuzz_round2.py [cases] [seed] [wide|espcn|gemm|small_ops]"""
+srx_gemm, max-pooling, the stride-2 sample map, channel normalisation, patch extraction, srx_texture_gram(_bwd),
+srx_conv3x3_blocked_bwd_filter.
+Usage: fuzz_round2.py [cases] [seed] [wide|espcn|gemm|small_ops|texture|blocked_wgrad]"""
 import os, sys
 import numpy as np
 import torch
@@ -116,10 +117,55 @@ def case_small_ops(rng):
     return None
 
 
+def case_texture(rng):
+    """srx_texture_gram / _bwd against float64 (enet/enet/model_enet.py:34-41, 225-259)."""
+    c = [64, 128, 256][rng.integers(3)]
+    n, ph, pw = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    h, w = 16 * ph, 16 * pw
+    tag = 'texture N%d %dx%d C%d' % (n, h, w, c)
+    x = (np.abs(rng.normal(size=(n, h, w, c))) * (rng.random((n, h, w, c)) < 0.7) + 0.01).astype(np.float32)
+    g = ops.texture_gram(dev(x))
+    x64 = x.astype(np.float64)
+    m = x64.mean(axis=-1, keepdims=True) + 1e-6
+    pat = (x64 / m).reshape(n, ph, 16, pw, 16, c).transpose(0, 1, 3, 2, 4, 5).reshape(-1, 256, c)
+    if bad(npy(g), np.einsum('pki,pkj->pij', pat, pat)):
+        return tag + ': gram'
+    dg = rng.normal(size=(n * ph * pw, c, c)).astype(np.float32)
+    dg = (dg + dg.transpose(0, 2, 1)) * 0.5
+    dx = ops.texture_gram_bwd(dev(x), dev(dg))
+    dn = 2.0 * np.einsum('pkj,pjc->pkc', pat, dg.astype(np.float64))
+    dn = dn.reshape(n, ph, pw, 16, 16, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, h, w, c)
+    if bad(npy(dx), dn / m - (dn * x64).sum(axis=-1, keepdims=True) / (c * m * m)):
+        return tag + ': gradient'
+    return None
+
+
+def case_blocked_wgrad(rng):
+    """srx_conv3x3_blocked_bwd_filter (all block pairs in one launch, or the per-pair fallback) against float64 sums."""
+    cib, cob = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    n, h = int(rng.integers(1, 6)), int(rng.integers(1, 20))
+    w = int(rng.integers(1, 140 if rng.random() < 0.2 else 40))
+    tag = 'blocked wgrad %dx%d blocks N%d %dx%d' % (cib, cob, n, h, w)
+    x = rng.normal(size=(cib, n, h, w, 64)).astype(np.float32)
+    dp = rng.normal(size=(cob, n, h, w, 64)).astype(np.float32)
+    dw = torch.full((cib, cob, 3, 3, 64, 64), float('nan'), device='cuda')
+    db = torch.full((cob * 64,), float('nan'), device='cuda')
+    ops.conv3x3_blocked_bwd_filter(dev(x), dev(dp), dw, db)
+    if bad(npy(db), dp.astype(np.float64).sum(axis=(1, 2, 3)).reshape(-1)):
+        return tag + ': bias gradient'
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1), (0, 0)))
+    ib, ob = int(rng.integers(cib)), int(rng.integers(cob))
+    ref = np.stack([np.stack([np.einsum('nhwi,nhwo->io', xp[ib][:, kh:kh + h, kw:kw + w, :], dp[ob].astype(np.float64))
+                              for kw in range(3)]) for kh in range(3)])
+    if bad(npy(dw[ib, ob]), ref):
+        return tag + ': pair (%d, %d)' % (ib, ob)
+    return None
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    kinds = [case_wide, case_espcn, case_gemm, case_small_ops]
+    kinds = [case_wide, case_espcn, case_gemm, case_small_ops, case_texture, case_blocked_wgrad]
     if len(sys.argv) > 3:          # fuzz_round2.py cases seed wide|espcn|gemm|small_ops: one kind only
         kinds = [k for k in kinds if k.__name__ == 'case_' + sys.argv[3]]
     nbad = 0
