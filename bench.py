@@ -258,15 +258,18 @@ def extras(model, dev, stream, x64, y64, px):
         del em, sdb, bqb, hdb
         # the tile shape BASELINE's config names: 512x512 HR tiles, 4 per GPU (the discriminator's first dense layer
         # grows to 16*16*512 inputs)
-        nt = 4
-        em = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0), device=dev, seed=1, image_size=512)
-        sdb, bqb, hdb = next(enet_train.synthetic_batches(nt, dev, hd_size=512))
-        em.g_step(sdb, bqb, hdb); em.d_step(sdb, bqb, hdb)
-        g_ms = hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream)
-        d_ms = hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream)
-        out['enet_pat']['tiles_512'] = {'batch': nt, 'patch': '128->512', 'g_trainer_ms': round(g_ms, 2), 'd_trainer_ms': round(d_ms, 2),
-                                        'g_trainer_frac_of_fp32_mfma_peak': round(16 * nt / nb * flop / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
-        del em
+        try:
+            nt = 4
+            em = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0), device=dev, seed=1, image_size=512)
+            sdb, bqb, hdb = next(enet_train.synthetic_batches(nt, dev, hd_size=512))
+            em.g_step(sdb, bqb, hdb); em.d_step(sdb, bqb, hdb)
+            g_ms = hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream)
+            d_ms = hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream)
+            out['enet_pat']['tiles_512'] = {'batch': nt, 'patch': '128->512', 'g_trainer_ms': round(g_ms, 2), 'd_trainer_ms': round(d_ms, 2),
+                                            'g_trainer_frac_of_fp32_mfma_peak': round(16 * nt / nb * flop / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
+            del em
+        except Exception as exc:
+            out['enet_pat']['tiles_512'] = {'error': repr(exc)}
     except Exception as exc:             # a secondary number must never take the primary line down
         out['enet_pat'] = {'error': repr(exc)}
     return out
