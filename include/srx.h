@@ -320,6 +320,22 @@ int srx_texture_gram(const float* x, float* gram, int N, int H, int W, int C, fl
 int srx_texture_gram_bwd(const float* x, const float* dgram, float* dx, int N, int H, int W, int C, float eps, float alpha,
                          srx_stream_t stream);
 
+/* The reference's uint8 image resizes, byte for byte: scipy.misc.imresize (enet/enet/datasets.py:110-111: 25 % bilinear
+ * down, 400 % bicubic up; enet/enet/experiment_resolve.py:78-79: 400 % bicubic) is Pillow's Image.resize on the uint8
+ * image -- two passes (horizontal, then vertical) of  out = clip8((2^21 + sum_k kk[k] * in[xmin + k]) >> 22)  with
+ * integer coefficients (libImaging/Resample.c).  Pinned by the reference's own output, assets/enet_eagle_bq.png.
+ *   srx_pil_resample_ksize / _coeffs: the coefficient tables of one axis, computed on the HOST in double precision as
+ *     Pillow does: bounds [out_size][2] = (first input index, count), kk [out_size][ksize].
+ *   srx_resample_u8: one pass on the device over [outer][in_size][inner] -> [outer][out_size][inner] (horizontal pass of
+ *     an [N,H,W,C] image: outer = N*H, inner = C; vertical: outer = N, inner = W*C); bounds / kk are DEVICE copies.
+ *   srx_u8_to_pm1: astype(float32) / 127.5 - 1.0 (two roundings). */
+typedef enum { SRX_RESAMPLE_BILINEAR = 0, SRX_RESAMPLE_BICUBIC = 1 } srx_resample_filter;
+int srx_pil_resample_ksize(int in_size, int out_size, int filter);
+int srx_pil_resample_coeffs(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk);
+int srx_resample_u8(const uint8_t* in, uint8_t* out, long outer, int in_size, int out_size, long inner,
+                    const int32_t* bounds, const int32_t* kk, int ksize, srx_stream_t stream);
+int srx_u8_to_pm1(const uint8_t* in, float* out, size_t n, srx_stream_t stream);
+
 /* tf.nn.max_pool(ksize 2x2, strides 2x2, padding='SAME') (enet/enet/model_vgg.py:28-36): [N,H,W,C] ->
  * [N,ceil(H/2),ceil(W/2),C], C % 4 == 0.  _bwd = MaxPoolGrad given the forward INPUT x: the gradient of a window goes
  * to its first maximum in scan order. */

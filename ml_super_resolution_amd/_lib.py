@@ -28,7 +28,7 @@ EXPORTS = [
     'srx_conv2d_bwd_data_acc', 'srx_conv3x3_blocked', 'srx_conv3x3_blocked_bwd_filter_workspace_bytes', 'srx_conv3x3_blocked_bwd_filter',
     'srx_espcn_forward', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_subsample2', 'srx_subsample2_bwd',
     'srx_channel_blocks_to_nhwc', 'srx_nhwc_to_channel_blocks', 'srx_channel_normalize', 'srx_channel_normalize_bwd',
-    'srx_extract_patches16', 'srx_texture_gram', 'srx_texture_gram_bwd', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_resize_bicubic_tf', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
+    'srx_extract_patches16', 'srx_texture_gram', 'srx_texture_gram_bwd', 'srx_pil_resample_ksize', 'srx_pil_resample_coeffs', 'srx_resample_u8', 'srx_u8_to_pm1', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_resize_bicubic_tf', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
 ]
 
 
@@ -108,6 +108,10 @@ def lib():
     L.srx_conv3x3_blocked_bwd_filter.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, sz, vp]
     L.srx_texture_gram.argtypes = [vp, vp, i, i, i, i, f, vp]
     L.srx_texture_gram_bwd.argtypes = [vp, vp, vp, i, i, i, i, f, f, vp]
+    L.srx_pil_resample_ksize.argtypes = [i, i, i]
+    L.srx_pil_resample_coeffs.argtypes = [i, i, i, vp, vp]
+    L.srx_resample_u8.argtypes = [vp, vp, ctypes.c_long, i, i, ctypes.c_long, vp, vp, i, vp]
+    L.srx_u8_to_pm1.argtypes = [vp, vp, sz, vp]
     L.srx_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
     L.srx_maxpool2x2_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.srx_subsample2.argtypes = [vp, vp, i, i, i, i, i, i, vp]

@@ -58,19 +58,21 @@ def extract_model(FLAGS):
     print('wrote {} generator variables to {}'.format(len(keep), target))
 
 
-def source_images(FLAGS):
-    """The directory walk and the bicubic 4x of :61-93 (scipy.misc.imresize(image, 400, 'bicubic') is PIL's
-    bicubic resize of the uint8 image)."""
+def source_images(FLAGS, device):
+    """The directory walk and the bicubic 4x of :61-93.  scipy.misc.imresize(image, 400, 'bicubic') is Pillow's
+    bicubic resize of the uint8 image: here on the GPU, byte for byte (ops.resize_pil_u8; the file decode stays on the
+    host), followed by the reference's / 127.5 - 1."""
     from PIL import Image
     for file_name in sorted(os.listdir(FLAGS.source_dir_path)):
         name, ext = os.path.splitext(file_name)
         if ext.lower() not in ['.png', '.jpg', '.jpeg']:
             continue
-        sd = Image.open(os.path.join(FLAGS.source_dir_path, file_name)).convert('RGB')
-        bq = sd.resize((sd.width * 4, sd.height * 4), Image.BICUBIC)
+        sd = np.array(Image.open(os.path.join(FLAGS.source_dir_path, file_name)).convert('RGB'))     # (a writable copy)
+        sd_u8 = torch.from_numpy(sd[None]).to(device)
+        bq_u8 = ops.resize_pil_u8(sd_u8, sd.shape[0] * 4, sd.shape[1] * 4, 'bicubic')
         yield {
-            'sd_image': np.asarray(sd).astype(np.float32)[None] / 127.5 - 1.0,
-            'bq_image': np.asarray(bq).astype(np.float32)[None] / 127.5 - 1.0,
+            'sd_image': ops.u8_to_pm1(sd_u8),
+            'bq_image': ops.u8_to_pm1(bq_u8),
             'bq_path': os.path.join(FLAGS.target_dir_path, name + '_bq.png'),
             'sr_path': os.path.join(FLAGS.target_dir_path, name + '_sr.png'),
         }
@@ -85,9 +87,8 @@ def super_resolve(FLAGS):
     device = torch.device('cuda')
     g = load_generator(prefix, device)
     os.makedirs(FLAGS.target_dir_path, exist_ok=True)
-    for images in source_images(FLAGS):
-        sd = torch.from_numpy(images['sd_image']).to(device)
-        bq = torch.from_numpy(images['bq_image']).to(device)
+    for images in source_images(FLAGS, device):
+        sd, bq = images['sd_image'], images['bq_image']
         sr = g.forward(sd, bq)
         # saturate_cast(x * 127.5 + 127.5): clamp, then truncate
         Image.fromarray(ops.saturate_u8(sr)[0].cpu().numpy()).save(images['sr_path'])

@@ -8,9 +8,9 @@ log_path, model='pat', batch_size=64` (:164-170) and the alternating schedule of
 
 A checkpoint (`tf.train.Saver` format and names, model_enet.EnetModel.save_tf_checkpoint) is written whenever
 step % 1000 == 999 (:116-117) and the latest one is restored at start (:96-110).
-Batches are (sd 32x32, bq 128x128, hd 128x128) in [-1, 1] (experiment_train.py:15-22); the reference decodes a
-directory of images on the host (enet/enet/datasets.py); here `--train_dir_path` may be an .npz of {'sd','bq','hd'}
-or absent (synthetic batches).  VGG-19 weights: the .npz the reference downloads (`--vgg19_path`); when it is absent
+Batches are (sd 32x32, bq 128x128, hd 128x128) in [-1, 1] (experiment_train.py:15-22).  `--train_dir_path`: a directory
+of images as in the reference (enet/enet/datasets.py, mirrored in datasets.py: decode and crop on the host, the 25 % /
+400 % resizes on the GPU, byte for byte), or an .npz of {'sd','bq','hd'}, or absent (synthetic batches).  VGG-19 weights: the .npz the reference downloads (`--vgg19_path`); when it is absent
 and `--allow_random_vgg true`, VGG-shaped random weights (timing / smoke runs only).
 With WORLD_SIZE > 1 (torchrun) the batch is sharded and the gradients of BOTH trainers are all-reduced (one flat
 buffer each), as SURVEY 8e prescribes for config 5.
@@ -92,8 +92,15 @@ def main(argv=None, log=None):
     if world > 1:
         srx_dist.attach_flat(m, world)
     per_rank = FLAGS.batch_size // world
-    batches = (npz_batches(FLAGS.train_dir_path, per_rank, device, seed=rank) if FLAGS.train_dir_path
-               else synthetic_batches(per_rank, device, seed=rank))
+    if FLAGS.train_dir_path and os.path.isdir(FLAGS.train_dir_path):
+        # the reference's data path (enet/enet/datasets.py:79-127): crops on the host, both resizes and the float map on
+        # the GPU, byte for byte what scipy.misc.imresize gives (each rank walks the directory with its own seed)
+        from . import datasets
+        batches = datasets.image_batches(FLAGS.train_dir_path, 4, per_rank, device, rng=np.random.RandomState(1234 + rank))
+    elif FLAGS.train_dir_path:
+        batches = npz_batches(FLAGS.train_dir_path, per_rank, device, seed=rank)
+    else:
+        batches = synthetic_batches(per_rank, device, seed=rank)
     while True:
         step = m.global_step
         if FLAGS.stop_training_at_k_step is not None and step >= FLAGS.stop_training_at_k_step:

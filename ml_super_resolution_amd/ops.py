@@ -275,6 +275,64 @@ def u8_to_unit_float(x):
     return out
 
 
+RESAMPLE_FILTERS = {'bilinear': 0, 'bicubic': 1}
+_resample_tables = {}
+
+
+def pil_resample_coeffs(in_size, out_size, filt):
+    """Pillow's coefficient tables for one axis (srx_pil_resample_coeffs): (bounds int32 [out, 2], kk int32 [out, ksize])."""
+    import numpy as np
+    f = RESAMPLE_FILTERS[filt]
+    ksize = lib().srx_pil_resample_ksize(in_size, out_size, f)
+    if ksize < 0:
+        raise ValueError('bad resample sizes %d -> %d' % (in_size, out_size))
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    check(lib().srx_pil_resample_coeffs(in_size, out_size, f, ctypes.c_void_p(bounds.ctypes.data), ctypes.c_void_p(kk.ctypes.data)),
+          'srx_pil_resample_coeffs')
+    return bounds, kk
+
+
+def _device_tables(in_size, out_size, filt, device):
+    key = (in_size, out_size, filt, str(device))
+    t = _resample_tables.get(key)
+    if t is None:
+        b, k = pil_resample_coeffs(in_size, out_size, filt)
+        t = _resample_tables[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), k.shape[1])
+    return t
+
+
+def resize_pil_u8(x, out_h, out_w, filt='bicubic'):
+    """scipy.misc.imresize / PIL.Image.resize of uint8 images on the GPU, byte for byte: x [N,H,W,C] uint8 ->
+    [N,out_h,out_w,C] uint8; two passes of srx_resample_u8 (horizontal, then vertical), the intermediate in uint8."""
+    if not x.is_cuda or x.dtype != torch.uint8 or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError('x must be a contiguous uint8 [N,H,W,C] tensor on the GPU')
+    N, H, W, C = x.shape
+    t = x
+    if out_w != W:
+        b, k, ks = _device_tables(W, out_w, filt, x.device)
+        t2 = torch.empty((N, H, out_w, C), dtype=torch.uint8, device=x.device)
+        check(lib().srx_resample_u8(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t2.data_ptr()), N * H, W, out_w, C,
+                                    ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(k.data_ptr()), ks, _stream()), 'srx_resample_u8')
+        t = t2
+    if out_h != H:
+        b, k, ks = _device_tables(H, out_h, filt, x.device)
+        t2 = torch.empty((N, out_h, t.shape[2], C), dtype=torch.uint8, device=x.device)
+        check(lib().srx_resample_u8(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t2.data_ptr()), N, H, out_h, t.shape[2] * C,
+                                    ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(k.data_ptr()), ks, _stream()), 'srx_resample_u8')
+        t = t2
+    return t if t is not x else x.clone()
+
+
+def u8_to_pm1(x):
+    """uint8 -> float32 in [-1, 1]: astype(float32) / 127.5 - 1.0 (two roundings), as the reference's data pipelines do."""
+    if not x.is_cuda or x.dtype != torch.uint8 or not x.is_contiguous():
+        raise ValueError('x must be a contiguous uint8 tensor on the GPU')
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().srx_u8_to_pm1(ctypes.c_void_p(x.data_ptr()), _ptr(out), x.numel(), _stream()), 'srx_u8_to_pm1')
+    return out
+
+
 def gaussian_blur(x, sigma):
     """skimage.filters.gaussian(x, sigma, mode='nearest') on [N,H,W,C]."""
     _chk(x, 'x')

@@ -658,3 +658,82 @@ def c_vdsr_train_step_grads(sd, hd, params, weight_decay=1e-4):
             dx = c_conv2d_bwd_data(dpre, k, acts[i].shape[1:3], 'SAME')
             dpre = c_act_bwd(dx, acts[i], 'relu')
     return mse + reg, grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scipy.misc.imresize on uint8 images = Pillow's Image.resize (enet/enet/datasets.py:110-111, enet/enet/
+# experiment_resolve.py:78-79).  Pillow is a dependency of the reference (through scipy.misc; version not pinned by
+# the reference, the algorithm below is libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+# ImagingResampleHorizontal_8bpc / Vertical_8bpc).  Pinned twice: against Pillow itself where it is installed
+# (tests/test_oracle_pins.py) and against the reference's own output assets/enet_eagle_bq.png (P5).
+# ---------------------------------------------------------------------------------------------------------------------
+def _pil_filter(name):
+    def bilinear(x):
+        x = abs(x)
+        return 1.0 - x if x < 1.0 else 0.0
+
+    def bicubic(x, a=-0.5):
+        x = abs(x)
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+    return {'bilinear': (bilinear, 1.0), 'bicubic': (bicubic, 2.0)}[name]
+
+
+def pil_resample_coeffs(in_size, out_size, filt):
+    """(bounds int64 [out, 2] = (first input index, count), kk int64 [out, ksize]): Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc (22 fractional bits)."""
+    f, sup = _pil_filter(filt)
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = sup * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int64)
+    kk = np.zeros((out_size, ksize), np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([f((x + xmin - center + 0.5) * ss) for x in range(xmax)], np.float64)
+        ww = 0.0
+        for v in w:                     # (the C loop adds them one by one)
+            ww += v
+        if ww != 0.0:
+            w = w / ww
+        for x in range(xmax):
+            v = w[x] * (1 << 22)
+            kk[xx, x] = int(-0.5 + v) if w[x] < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _pil_resample_axis(img, out_size, axis, filt):
+    x = np.moveaxis(img, axis, 0).astype(np.int64)
+    bounds, kk = pil_resample_coeffs(x.shape[0], out_size, filt)
+    out = np.empty((out_size,) + x.shape[1:], np.int64)
+    for o in range(out_size):
+        xmin, n = bounds[o]
+        out[o] = np.clip(((1 << 21) + np.tensordot(kk[o, :n], x[xmin:xmin + n], axes=(0, 0))) >> 22, 0, 255)
+    return np.moveaxis(out.astype(np.uint8), 0, axis)
+
+
+def pil_resize_u8(img, out_h, out_w, filt='bicubic'):
+    """PIL.Image.fromarray(img).resize((out_w, out_h), filt) for uint8 [H,W,C] or [N,H,W,C]: horizontal pass, then
+    vertical, the intermediate in uint8."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    h_axis = img.ndim - 3
+    t = img
+    if out_w != img.shape[h_axis + 1]:
+        t = _pil_resample_axis(t, out_w, h_axis + 1, filt)
+    if out_h != img.shape[h_axis]:
+        t = _pil_resample_axis(t, out_h, h_axis, filt)
+    return t
+
+
+def u8_to_pm1(x):
+    """astype(float32) / 127.5 - 1.0 (enet/enet/datasets.py:113-115)."""
+    return np.asarray(x).astype(np.float32) / np.float32(127.5) - np.float32(1.0)

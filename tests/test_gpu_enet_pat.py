@@ -577,3 +577,18 @@ def test_texture_gram_one_pass_against_the_three_launches_and_float64(c, n, h, w
     m = x64.mean(axis=-1, keepdims=True) + 1e-6
     dref = dn / m - (dn * x64).sum(axis=-1, keepdims=True) / (c * m * m)
     close(dx, dref)
+
+
+def test_enet_train_script_reads_a_directory_of_images(tmp_path):
+    """`--train_dir_path <directory>`: the reference's own data path (enet/enet/datasets.py) feeding the trainers --
+    three generator steps and the discriminator step of the schedule on crops of real files."""
+    from PIL import Image
+    from ml_super_resolution_amd.enet import experiment_train
+    rng = np.random.default_rng(3)
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)).save(str(tmp_path / ('img%d.png' % i)))
+    log = []
+    m = experiment_train.main(['--model', 'pat', '--batch_size', '2', '--stop_training_at_k_step', '3', '--allow_random_vgg', 'true',
+                               '--train_dir_path', str(tmp_path)], log=log.append)
+    assert m.global_step == 3
+    assert all(np.isfinite(v) for rec in log for v in rec.values() if isinstance(v, float))

@@ -1,4 +1,6 @@
 """ESPCN and SRCNN through the reference-shaped entry points, against golden vectors / the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -335,3 +337,57 @@ def test_srcnn_script_train_checkpoint_resume_and_panel(tmp_path):
     assert px.shape == (231, 693, 3) and Image.open(out).size == (693, 231)
     # the sd strip of the panel is TensorFlow's bicubic of the hd strip's source crop: both strips differ, both are images
     assert np.abs(px[:, :231].astype(int) - px[:, 231:462].astype(int)).mean() > 0.5
+
+
+@pytest.mark.parametrize('filt', ['bilinear', 'bicubic'])
+def test_resize_pil_u8_on_the_device_is_byte_exact(filt):
+    """ops.resize_pil_u8 (srx_pil_resample_coeffs on the host + two integer passes of srx_resample_u8) against the
+    oracle's restatement of Pillow's resample -- the reference's scipy.misc.imresize -- byte for byte; and
+    astype(float32) / 127.5 - 1."""
+    from ml_super_resolution_amd import ops
+    rng = np.random.default_rng(23)
+    for n, h, w, oh, ow in ((3, 128, 128, 32, 32), (2, 32, 32, 128, 128), (1, 90, 51, 22, 12), (2, 40, 40, 57, 33), (1, 64, 64, 64, 16),
+                            (1, 17, 23, 17, 92)):
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        got = ops.resize_pil_u8(torch.from_numpy(img).cuda(), oh, ow, filt)
+        assert got.dtype == torch.uint8 and tuple(got.shape) == (n, oh, ow, 3)
+        np.testing.assert_array_equal(got.cpu().numpy(), O.pil_resize_u8(img, oh, ow, filt))
+    x = torch.arange(256, dtype=torch.uint8).cuda()
+    np.testing.assert_array_equal(ops.u8_to_pm1(x).cpu().numpy(), O.u8_to_pm1(np.arange(256, dtype=np.uint8)))
+
+
+def test_enet_datasets_image_batches(tmp_path):
+    """enet/enet/datasets.py:79-127 on the device: random 128x128 crops, 25 % bilinear down, 400 % bicubic up, / 127.5 - 1 --
+    the same bytes as scipy.misc.imresize (= Pillow) on the host, with the reference's random-number calls in order."""
+    from PIL import Image
+    from ml_super_resolution_amd.enet import datasets
+    rng = np.random.default_rng(29)
+    images = {}
+    for name in ('a.png', 'b.jpg', 'c.PNG'):
+        images[name] = rng.integers(0, 256, (260, 300, 3), dtype=np.uint8)
+        Image.fromarray(images[name]).save(str(tmp_path / name), quality=95)
+    (tmp_path / 'readme.txt').write_text('not an image')
+    it = datasets.image_batches(str(tmp_path), 4, batch_size=5, device='cuda', rng=np.random.RandomState(7))
+    sd, bq, hd = next(it)
+    assert tuple(sd.shape) == (5, 32, 32, 3) and tuple(bq.shape) == (5, 128, 128, 3) and tuple(hd.shape) == (5, 128, 128, 3)
+    # the same walk on the host
+    ref_rng = np.random.RandomState(7)
+    names = sorted(n for n in os.listdir(str(tmp_path)) if datasets.is_image_name(n))
+
+    def walk():
+        while True:
+            ref_rng.shuffle(names)
+            for n in names:
+                yield n
+    order = walk()
+    for i in range(5):
+        full = np.asarray(Image.open(str(tmp_path / next(order))).convert('RGB'))
+        x, y = ref_rng.randint(128), ref_rng.randint(128)
+        crop = full[y:y + 128, x:x + 128]
+        s8 = np.asarray(Image.fromarray(crop).resize((32, 32), Image.BILINEAR))
+        b8 = np.asarray(Image.fromarray(s8).resize((128, 128), Image.BICUBIC))
+        np.testing.assert_array_equal(hd[i].cpu().numpy(), O.u8_to_pm1(crop))
+        np.testing.assert_array_equal(sd[i].cpu().numpy(), O.u8_to_pm1(s8))
+        np.testing.assert_array_equal(bq[i].cpu().numpy(), O.u8_to_pm1(b8))
+    sd2, _, _ = next(it)
+    assert tuple(sd2.shape) == (5, 32, 32, 3)

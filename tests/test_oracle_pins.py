@@ -147,3 +147,33 @@ def test_p6_tf_bicubic_resize_reproduces_the_reference_panels():
     # identity at scale 1; constants stay constant (the four weights sum to one at every table offset)
     np.testing.assert_allclose(O.resize_bicubic_tf(x, 12, 9), x, atol=1e-15)
     np.testing.assert_allclose(O.resize_bicubic_tf(np.full((1, 5, 7, 1), 3.25), 13, 11), 3.25, atol=1e-12)
+
+
+def test_pil_resize_restatement_equals_pillow_the_p5_bytes_and_the_library_tables():
+    """scipy.misc.imresize = Pillow's Image.resize on uint8 (enet/enet/datasets.py:110-111: 25 % bilinear, 400 %
+    bicubic; enet/enet/experiment_resolve.py:78-79).  The oracle's restatement of libImaging/Resample.c
+    (O.pil_resize_u8) against Pillow itself, against the reference's own assets/enet_eagle_bq.png bytes (P5), and the
+    coefficient tables the library computes on the host (srx_pil_resample_coeffs, no GPU involved) against the
+    oracle's."""
+    from PIL import Image
+    from ml_super_resolution_amd import ops
+    rng = np.random.default_rng(17)
+    for filt, pf in (('bilinear', Image.BILINEAR), ('bicubic', Image.BICUBIC)):
+        for h, w, oh, ow in ((128, 128, 32, 32), (32, 32, 128, 128), (90, 51, 22, 12), (40, 40, 57, 33), (7, 5, 28, 20)):
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            ref = np.asarray(Image.fromarray(img).resize((ow, oh), pf))
+            np.testing.assert_array_equal(O.pil_resize_u8(img, oh, ow, filt), ref)
+        for a, b in ((128, 32), (32, 128), (224, 896), (90, 22), (40, 57), (1, 5), (5, 1), (300, 301)):
+            ob, ok = O.pil_resample_coeffs(a, b, filt)
+            lb, lk = ops.pil_resample_coeffs(a, b, filt)
+            np.testing.assert_array_equal(lb, ob)
+            np.testing.assert_array_equal(lk, ok)
+    z = np.load(os.path.join(GOLDEN, 'pin_p5_eagle_crop.npz'))
+    src, ref = z['source'], z['reference_bq']
+    m = P5_MARGIN
+    np.testing.assert_array_equal(O.pil_resize_u8(src, src.shape[0] * 4, src.shape[1] * 4, 'bicubic')[m:-m, m:-m], ref[m:-m, m:-m])
+    # batches resize image by image
+    batch = rng.integers(0, 256, (3, 20, 24, 3), dtype=np.uint8)
+    got = O.pil_resize_u8(batch, 5, 6, 'bilinear')
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], np.asarray(Image.fromarray(batch[i]).resize((6, 5), Image.BILINEAR)))
