@@ -2,8 +2,8 @@
 """Random-shape parity sweep of the round-2 entry points against NumPy float64 / the oracle (a development tool; the
 committed cases live in tests/): srx_conv3x3_blocked (forward, data gradient, fused mask), srx_espcn_forward,
 srx_gemm, max-pooling, the stride-2 sample map, channel normalisation, patch extraction, srx_texture_gram(_bwd),
-srx_conv3x3_blocked_bwd_filter.
-Usage: fuzz_round2.py [cases] [seed] [wide|espcn|gemm|small_ops|texture|blocked_wgrad]"""
+srx_conv3x3_blocked_bwd_filter, srx_resample_u8.
+Usage: fuzz_round2.py [cases] [seed] [wide|espcn|gemm|small_ops|texture|blocked_wgrad|resample]"""
 import os, sys
 import numpy as np
 import torch
@@ -162,10 +162,24 @@ def case_blocked_wgrad(rng):
     return None
 
 
+def case_resample(rng):
+    """ops.resize_pil_u8 (Pillow's integer resample on the GPU) against the oracle's restatement, byte for byte."""
+    filt = ['bilinear', 'bicubic'][rng.integers(2)]
+    n, c = int(rng.integers(1, 4)), [1, 3, 4][rng.integers(3)]
+    h, w, oh, ow = (int(rng.integers(1, 90)) for _ in range(4))
+    img = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+    if rng.random() < 0.2:
+        img[:] = [0, 255][rng.integers(2)]            # saturated images: the clipping paths
+    got = ops.resize_pil_u8(torch.from_numpy(img).cuda(), oh, ow, filt).cpu().numpy()
+    if not np.array_equal(got, O.pil_resize_u8(img, oh, ow, filt)):
+        return 'resample %s N%d %dx%dx%d -> %dx%d' % (filt, n, h, w, c, oh, ow)
+    return None
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    kinds = [case_wide, case_espcn, case_gemm, case_small_ops, case_texture, case_blocked_wgrad]
+    kinds = [case_wide, case_espcn, case_gemm, case_small_ops, case_texture, case_blocked_wgrad, case_resample]
     if len(sys.argv) > 3:          # fuzz_round2.py cases seed wide|espcn|gemm|small_ops: one kind only
         kinds = [k for k in kinds if k.__name__ == 'case_' + sys.argv[3]]
     nbad = 0
