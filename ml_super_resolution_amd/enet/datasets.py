@@ -8,7 +8,8 @@ scipy.misc.imresize(hd, 25)` (Pillow BILINEAR, antialiased, to 32x32), `bq = sci
 (Pillow), the crops go to the GPU as uint8 and both resizes and the float conversion run there
 (`ops.resize_pil_u8`, `ops.u8_to_pm1`): the same bytes as the reference's CPU path (pinned by assets/enet_eagle_bq.png,
 tests/test_oracle_pins.py), without the per-image Python resizes on the training loop's critical path.
-(`build_image_batch_iterator`, the unused tf.data variant of :33-76, is not mirrored.)
+(`build_image_batch_iterator`, the unused tf.data variant of :33-76, is not mirrored.)  File decoding runs on a small
+thread pool a couple of batches ahead of the consumer.
 """
 import os
 
@@ -45,19 +46,41 @@ def degrade_on_device(hd_u8):
     return ops.u8_to_pm1(sd_u8), ops.u8_to_pm1(bq_u8), ops.u8_to_pm1(hd_u8)
 
 
-def image_batches(source_dir_path, scale_factor=4, batch_size=32, device='cuda', rng=None):
-    """(sd_images, bq_images, hd_images) device tensors, forever.  scale_factor is accepted and ignored, as in the
-    reference (:79: the 25 % / 400 % are literals)."""
+def _decode_crop(path, x, y):
     from PIL import Image
+    hd = np.asarray(Image.open(path).convert('RGB'))
+    crop = hd[y:y + 128, x:x + 128, :]
+    if crop.shape != (128, 128, 3):
+        raise ValueError('%s is smaller than 255 pixels on a side: crop %s' % (path, crop.shape))
+    return crop
+
+
+def image_batches(source_dir_path, scale_factor=4, batch_size=32, device='cuda', rng=None, workers=8, prefetch=2):
+    """(sd_images, bq_images, hd_images) device tensors, forever.  scale_factor is accepted and ignored, as in the
+    reference (:79: the 25 % / 400 % are literals).
+    The reference decodes its batch_size files one after the other inside the training loop (a 256x256 PNG costs a
+    millisecond or two: 64 of them are longer than a training step on this GPU).  Here the random numbers are drawn in
+    the reference's order on the calling thread, the decode + crop jobs they define run on `workers` threads (Pillow
+    releases the GIL) and `prefetch` batches are kept in flight: the same bytes, off the critical path."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
     rng = rng if rng is not None else np.random
     paths = build_path_generator(source_dir_path, rng)()
-    while True:
-        crops = np.empty((batch_size, 128, 128, 3), np.uint8)
-        for i in range(batch_size):
-            hd = np.asarray(Image.open(next(paths)).convert('RGB'))
-            x, y = rng.randint(128), rng.randint(128)
-            crop = hd[y:y + 128, x:x + 128, :]
-            if crop.shape != (128, 128, 3):
-                raise ValueError('image smaller than 255 pixels on a side: crop %s' % (crop.shape,))
-            crops[i] = crop
-        yield degrade_on_device(torch.from_numpy(crops).to(device))
+    pool = ThreadPoolExecutor(max_workers=max(1, workers))
+
+    def submit_batch():
+        jobs = []
+        for _ in range(batch_size):
+            path = next(paths)
+            x, y = rng.randint(128), rng.randint(128)          # (:104-105, in this order)
+            jobs.append(pool.submit(_decode_crop, path, x, y))
+        return jobs
+    pending = collections.deque(submit_batch() for _ in range(max(1, prefetch)))
+    try:
+        while True:
+            jobs = pending.popleft()
+            pending.append(submit_batch())
+            crops = np.stack([j.result() for j in jobs], axis=0)
+            yield degrade_on_device(torch.from_numpy(crops).to(device))
+    finally:
+        pool.shutdown(wait=False, cancel_futures=True)
