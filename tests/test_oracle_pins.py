@@ -177,3 +177,127 @@ def test_pil_resize_restatement_equals_pillow_the_p5_bytes_and_the_library_table
     got = O.pil_resize_u8(batch, 5, 6, 'bilinear')
     for i in range(3):
         np.testing.assert_array_equal(got[i], np.asarray(Image.fromarray(batch[i]).resize((6, 5), Image.BILINEAR)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# P7: the reference's own feature maps (assets/vdsr-fig2-*.png) pin the convolution of rows A1 / A2
+# ----------------------------------------------------------------------------------------------------------------
+def p7_load():
+    return np.load(os.path.join(GOLDEN, 'pin_p7_vdsr_fig2.npz'))
+
+
+def p7_decode(u8):
+    """Midpoint of the code's interval under saturate_cast(x * 127.5 + 127.5) (truncation)."""
+    return (u8.astype(np.float64) - 127.0) / 127.5
+
+
+def p7_masks(C):
+    """The fixture's four corners (top-left, top-right, bottom-left, bottom-right) of the 256 x 256 image as a batch
+    [4, C, C, ch].  A crop's two OUTER edges are real image borders (SAME padding acts there); its two inner edges
+    were cut out of the image, so the pixels on them miss neighbours and are excluded.  -> (valid, image-border)."""
+    valid = np.zeros((4, C, C), bool)
+    border = np.zeros((4, C, C), bool)
+    for i, (top, left) in enumerate([(1, 1), (1, 0), (0, 1), (0, 0)]):
+        valid[i, slice(0, C - 1) if top else slice(1, C), slice(0, C - 1) if left else slice(1, C)] = True
+        border[i, 0 if top else C - 1, :] = True
+        border[i, :, 0 if left else C - 1] = True
+    return valid, border & valid
+
+
+def p7_fitted(z, n):
+    """Output channels of layer n the fit had enough active pixels for (4 equations per unknown); the others are
+    maps that are dead (or nearly) on this image: nothing to predict."""
+    return z['n_fit%d' % n] >= 4 * (9 * z['w%d' % n].shape[2] + 1)
+
+
+# Layers whose maps carry signal through the 8-bit encoding on BOTH sides.  The middle of this trained network
+# (layers 5-13) has activations below 6 levels of the encoding (max code 128-133): their PNGs hold no usable
+# numbers, and layers 14-16 are fitted from inputs of <= 15 levels, where the least-squares weights are attenuated
+# by the input's quantisation noise (errors in variables) and mispredict the border whatever the padding.
+P7_DECISIVE = (1, 2, 3, 17, 18, 19, 20)
+# mean |predicted code - reference code| in levels, measured at fixture time: interior / image border with zero
+# padding / with edge padding / with reflect padding
+P7_MEASURED = {1: (0.18, 0.17, 3.78, 3.78), 2: (0.36, 0.43, 1.60, 1.36), 3: (0.44, 0.45, 0.81, 0.90),
+               17: (0.17, 0.59, 1.18, 1.44), 18: (0.19, 0.54, 1.65, 2.10), 19: (0.19, 0.49, 1.57, 2.09),
+               20: (0.28, 0.35, 1.47, 1.30)}
+
+
+def p7_predict(z, n, conv, pad_mode='constant', relu=True, bias=True):
+    """Continuous code (y * 127.5 + 127.5) of layer n predicted from the reference's crop of layer n - 1."""
+    x = p7_decode(z['sd'] if n == 1 else z['conv%d' % (n - 1)])
+    w = z['w%d' % n].astype(np.float64)
+    b = z['b%d' % n].astype(np.float64) if bias else None
+    act = 'relu' if (n < 20 and relu) else None
+    if pad_mode == 'constant':
+        y = conv(x, w, b, 'SAME', act)
+    else:
+        y = conv(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)), mode=pad_mode), w, b, 'VALID', act)
+    return np.asarray(y, np.float64) * 127.5 + 127.5
+
+
+def p7_errors(z, n, cont):
+    ref = z['conv%d' % n].astype(np.float64)
+    valid, border = p7_masks(int(z['corner']))
+    f = p7_fitted(z, n)
+    err = np.abs(cont - (ref + 0.5))
+    return err[valid & ~border][:, f].mean(), err[border][:, f].mean()
+
+
+@pytest.mark.parametrize('n', P7_DECISIVE)
+def test_p7_reference_feature_maps_pin_conv_bias_relu_and_zero_same_padding(n):
+    """vdsr/vdsr/model_vdsr.py:47-106 on the reference's REAL activations.  The weights fitted on the rest of the image
+    (interior pixels only, tests/golden/make_pin_p7.py) predict the held-out corners -- image border included -- to
+    the encoding's quantisation noise when the oracle convolves with ZERO SAME padding, and miss the border by 2-20x
+    more with edge or reflect padding.  Dropping the bias breaks the interior; the ReLU clamp shows as a sign test."""
+    z = p7_load()
+    inner, brd = p7_errors(z, n, p7_predict(z, n, O.conv2d_fwd))
+    m = P7_MEASURED[n]
+    assert inner <= m[0] + 0.05 and brd <= m[1] + 0.05, (n, inner, brd)
+    assert inner <= 0.5 and brd <= 0.65
+    for mode, meas in (('edge', m[2]), ('reflect', m[3])):
+        inner_m, brd_m = p7_errors(z, n, p7_predict(z, n, O.conv2d_fwd, mode))
+        assert abs(inner_m - inner) < 1e-9                  # the padding only reaches the border pixels
+        assert brd_m >= meas - 0.05 and brd_m >= 1.75 * brd, (n, mode, brd_m, brd)
+    if n < 20:
+        # the ReLU clamp: the weights were fitted on ACTIVE pixels only; where their linear prediction goes below zero
+        # (code < 127) the reference's map shows exactly 127 = relu(negative) = 0.0 (29 % of layer 1's held-out pixels)
+        lin = p7_predict(z, n, O.conv2d_fwd, relu=False)
+        valid, _ = p7_masks(int(z['corner']))
+        f = p7_fitted(z, n)
+        neg = (lin < 127.0)[valid][:, f]
+        if n in (1, 2, 19):
+            assert neg.mean() > 0.05
+        if neg.any():
+            assert (z['conv%d' % n] == 127)[valid][:, f][neg].mean() >= 0.999
+        assert p7_errors(z, n, lin)[0] >= inner
+        no_bias, _ = p7_errors(z, n, p7_predict(z, n, O.conv2d_fwd, bias=False))
+        assert no_bias >= 1.5 * inner, (n, no_bias, inner)
+    # the C restatement (fp32), which is what bench.py times as the CPU baseline, agrees
+    cont_c = p7_predict(z, n, lambda x, w, b, p, a: O.c_conv2d_fwd(x, w, b, p, a))
+    assert np.abs(cont_c - p7_predict(z, n, O.conv2d_fwd)).max() < 1e-3
+
+
+def test_p7_encoded_bytes_and_the_chain_into_p3():
+    """Encoded with the truncating saturate_cast, the predictions land within one level of the reference's bytes, and
+    layer 20's prediction + the reference's sd crop gives the reference's sr crop (model_vdsr.py:104-106; P3's chain)."""
+    z = p7_load()
+    valid, _ = p7_masks(int(z['corner']))
+    for n in P7_DECISIVE:
+        enc = O.saturate_u8((p7_predict(z, n, O.conv2d_fwd) - 127.5) / 127.5).astype(np.int64)
+        ok = (np.abs(enc - z['conv%d' % n].astype(np.int64)) <= 1)[valid][:, p7_fitted(z, n)]
+        assert ok.mean() >= (0.999 if n in (1, 20) else 0.95), (n, ok.mean())
+    res = (p7_predict(z, 20, O.conv2d_fwd) - 127.5) / 127.5
+    sr = O.saturate_u8(p7_decode(z['sd']) + res).astype(np.int64)
+    d = np.abs(sr - z['sr'].astype(np.int64))[valid]
+    assert (d <= 1).mean() >= 0.99 and d.max() <= 2, ((d <= 1).mean(), d.max())
+
+
+def test_p7_every_layer_interior():
+    """All 20 layers, interior pixels: wherever the fit had data the prediction stays within a level on average (the
+    middle layers' maps are nearly empty -- at most 6 levels -- so this says little there; recorded for completeness)."""
+    z = p7_load()
+    for n in range(1, 21):
+        if not p7_fitted(z, n).any():
+            continue
+        inner, _ = p7_errors(z, n, p7_predict(z, n, O.conv2d_fwd))
+        assert inner <= 1.0, (n, inner)
