@@ -112,14 +112,63 @@ def shard(batch, rank, world_size):
     return batch[rank * per:(rank + 1) * per]
 
 
-def attach_flat(model, world_size):
+def _timed_hook(owner, world_size, timed):
+    """The gradient exchange as a hook; timed=True brackets every call with two events on the launch stream, kept in
+    `owner.allreduce_events` (read by allreduce_ms)."""
+    owner.allreduce_events = getattr(owner, 'allreduce_events', [])
+
+    def hook(g):
+        if timed and g.is_cuda:
+            s = torch.cuda.current_stream(g.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            allreduce_mean_(g, world_size)
+            e1.record(s)
+            owner.allreduce_events.append((e0, e1))
+        else:
+            allreduce_mean_(g, world_size)
+        return g
+    return hook
+
+
+def attach_flat(model, world_size, timed=False):
     """EnhanceNet (BASELINE config 5): two parameter groups, `g_` and `d_` (enet/enet/model_enet.py:331-343), each
-    one flat buffer -> one all-reduce(AVG) per trainer run.  Replicas start from rank 0's weights."""
-    bufs = [model.generator.params]
-    if getattr(model, 'discriminator', None) is not None:
-        bufs.append(model.discriminator.pool.params)
-    for b in bufs:
-        broadcast_(b, 0)
-    model.grad_hook_g = lambda g: allreduce_mean_(g, world_size)
-    model.grad_hook_d = lambda g: allreduce_mean_(g, world_size)
+    one flat buffer -> one all-reduce(AVG) per trainer run.  As attach() does for a ConvStack, EVERYTHING the schedule
+    and the optimizers depend on comes from rank 0: both parameter buffers, `global_step` (it decides which steps run
+    d_trainer -- experiment_train.py:112 -- and when to save / stop: ranks that disagree issue different collectives
+    and hang), both Adam step counts and both pairs of Adam slots."""
+    G = model.generator
+    D = getattr(model, 'discriminator', None)
+    P = D.pool if D is not None else None
+    broadcast_(G.params, 0)
+    if P is not None:
+        broadcast_(P.params, 0)
+    gs = model.g_state
+    head = torch.tensor([int(model.global_step), int(bool(gs)), int(gs.get('t', 0)) if gs else 0,
+                         int(P is not None and P.opt_m is not None), int(P.t) if P is not None else 0], dtype=torch.int64)
+    if td.get_backend() == 'nccl':
+        head = head.to(G.params.device)
+    td.broadcast(head, src=0)
+    step, has_g, g_t, has_d, d_t = (int(v) for v in head.tolist())
+    model.global_step = step
+    if has_g:
+        if not gs:
+            gs.update({'m': torch.zeros_like(G.params), 'v': torch.zeros_like(G.params)})
+        gs['t'] = g_t
+        broadcast_(gs['m'], 0)
+        broadcast_(gs['v'], 0)
+    else:
+        gs.clear()
+    if P is not None:
+        P.t = d_t
+        if has_d:
+            if P.opt_m is None:
+                P.opt_m, P.opt_v = torch.zeros_like(P.params), torch.zeros_like(P.params)
+            broadcast_(P.opt_m, 0)
+            broadcast_(P.opt_v, 0)
+        else:
+            P.opt_m = P.opt_v = None
+    model.allreduce_events = []
+    model.grad_hook_g = _timed_hook(model, world_size, timed)
+    model.grad_hook_d = _timed_hook(model, world_size, timed)
     return model

@@ -86,7 +86,7 @@ def main(argv=None, log=None):
     source = None
     if FLAGS.ckpt_path and os.path.isdir(FLAGS.ckpt_path):
         from .. import tf_bundle
-        source = tf_bundle.latest_checkpoint(FLAGS.ckpt_path)
+        source = tf_bundle.latest_checkpoint(FLAGS.ckpt_path, scan=True)     # (state file first, else the newest complete bundle)
     if source is not None:
         m.load_tf_checkpoint(source)
     if world > 1:

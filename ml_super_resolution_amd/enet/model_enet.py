@@ -470,12 +470,27 @@ class EnetModel(object):
         if self.discriminator is not None and self.discriminator.pool.opt_m is not None:
             out['beta1_power_1'] = np.asarray(0.9 ** (self.discriminator.pool.t + 1), dtype=np.float32)
             out['beta2_power_1'] = np.asarray(0.999 ** (self.discriminator.pool.t + 1), dtype=np.float32)
+            # not a TensorFlow variable (a Saver restoring by name ignores it): the count the powers stand for
+            out['srx/d_trainer_steps'] = np.asarray(self.discriminator.pool.t, dtype=np.int64)
         return out
 
     def save_tf_checkpoint(self, prefix):
         from .. import tf_bundle
         tf_bundle.save_checkpoint(prefix, self.tf_checkpoint_tensors())
         tf_bundle.update_checkpoint_state(prefix)
+
+    @staticmethod
+    def _d_steps_from_checkpoint(values, global_step):
+        """Adam step count of d_trainer.  In order: the explicit count this package writes beside the TensorFlow
+        variables; beta2_power_1 = 0.999 ** (t + 1), which stays a normal float32 for ~87,000 steps (float32 rounding
+        moves the recovered count by < 1e-4 of a step); the schedule of the training script (d_trainer on every third
+        step, experiment_train.py:112).  beta1_power_1 = 0.9 ** (t + 1) underflows after ~960 steps and is never used."""
+        if 'srx/d_trainer_steps' in values:
+            return int(values['srx/d_trainer_steps'])
+        b2p = float(values['beta2_power_1']) if 'beta2_power_1' in values else 0.0
+        if np.isfinite(b2p) and 1.2e-38 < b2p < 1.0:
+            return max(int(round(np.log(b2p) / np.log(0.999))) - 1, 0)
+        return (int(global_step) + 2) // 3
 
     def load_tf_checkpoint(self, prefix):
         """Restores the g_ / d_ variables, global_step and (when present) both optimizers' state."""
@@ -489,11 +504,13 @@ class EnetModel(object):
             self.g_state.update({'t': 0, 'm': torch.zeros_like(G.params), 'v': torch.zeros_like(G.params)})
         if have_d and D.pool.opt_m is None:
             D.pool.opt_m, D.pool.opt_v = torch.zeros_like(D.pool.params), torch.zeros_like(D.pool.params)
-        steps_of = lambda key, beta: int(round(np.log(float(values[key])) / np.log(beta))) - 1
         if have_g:
-            self.g_state['t'] = steps_of('beta1_power', 0.9) if 'beta1_power' in values else self.global_step
+            # g_trainer is the only op that increments global_step (model_enet.py:336-337): its Adam step count IS
+            # global_step.  (beta1_power = 0.9 ** (t + 1) cannot be inverted: it is 0.0 in float32 from t = 985 on, and
+            # the training script saves at step % 1000 == 999.)
+            self.g_state['t'] = self.global_step
         if have_d:
-            D.pool.t = steps_of('beta1_power_1', 0.9) if 'beta1_power_1' in values else (self.global_step + 2) // 3
+            D.pool.t = self._d_steps_from_checkpoint(values, self.global_step)
         for name, val, m, v, _, from_tf in self._named_buffers():
             if name not in values:
                 raise KeyError('checkpoint %s lacks variable %s' % (prefix, name))

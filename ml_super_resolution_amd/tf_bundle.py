@@ -25,6 +25,7 @@ Table format recap:  file = data blocks, metaindex block, index block, 48-byte f
   index block entry: key >= last key of a data block, value = BlockHandle (varint64 offset, varint64 size)
   footer  = metaindex BlockHandle, index BlockHandle, zero padding to 40 bytes, magic 0xdb4775248b80fb57 (LE)
 """
+import glob
 import os
 import struct
 
@@ -555,7 +556,9 @@ def save_checkpoint(prefix, tensors, num_shards=1, compress_index=False):
     if d:
         os.makedirs(d, exist_ok=True)
     items = []
-    files = [open(_data_path(prefix, s, num_shards), 'wb') for s in range(num_shards)]
+    # written under temporary names and renamed when complete, the index last: a prefix whose `.index` exists is whole
+    # (a run killed during a save leaves only `*.tmp` files behind)
+    files = [open(_data_path(prefix, s, num_shards) + '.tmp', 'wb') for s in range(num_shards)]
     offsets = [0] * num_shards
     try:
         for j, name in enumerate(sorted(tensors, key=lambda s: s.encode())):
@@ -576,14 +579,19 @@ def save_checkpoint(prefix, tensors, num_shards=1, compress_index=False):
             f.close()
     # BundleHeaderProto { num_shards; endianness = LITTLE (0, default: omitted); version { producer = 1 } }
     header = _pb_varint_field(1, num_shards) + _pb_bytes_field(3, _pb_varint_field(1, 1))
-    write_table(prefix + '.index', [(b'', header)] + items, compress=compress_index)
+    write_table(prefix + '.index.tmp', [(b'', header)] + items, compress=compress_index)
+    for sh in range(num_shards):
+        os.replace(_data_path(prefix, sh, num_shards) + '.tmp', _data_path(prefix, sh, num_shards))
+    os.replace(prefix + '.index.tmp', prefix + '.index')
 
 
-def update_checkpoint_state(prefix):
+def update_checkpoint_state(prefix, max_to_keep=5):
     """Writes `<dir>/checkpoint`, the CheckpointState text proto that tf.train.Saver.save maintains and
     tf.train.latest_checkpoint(dir) reads (vdsr/vdsr/experiment_train.py:108): the newest prefix as
-    `model_checkpoint_path`, every known prefix under `all_model_checkpoint_paths` (paths relative to the
-    directory, as the Saver writes them)."""
+    `model_checkpoint_path`, the known prefixes under `all_model_checkpoint_paths` (paths relative to the
+    directory, as the Saver writes them).  Like tf.train.Saver(max_to_keep=5) -- the default every script of the
+    reference uses -- at most `max_to_keep` prefixes stay listed and the files of the ones that drop off the list are
+    deleted.  The state file itself is replaced atomically."""
     d = os.path.dirname(os.path.abspath(prefix))
     name = os.path.basename(prefix)
     state = os.path.join(d, 'checkpoint')
@@ -594,25 +602,55 @@ def update_checkpoint_state(prefix):
             if line.startswith('all_model_checkpoint_paths:'):
                 known.append(line.split(':', 1)[1].strip().strip('"'))
     known = [k for k in known if k != name] + [name]
-    with open(state, 'w') as f:
+    dropped = known[:-max_to_keep] if max_to_keep and len(known) > max_to_keep else []
+    known = known[len(dropped):]
+    with open(state + '.tmp', 'w') as f:
         f.write('model_checkpoint_path: "%s"\n' % name)
         for k in known:
             f.write('all_model_checkpoint_paths: "%s"\n' % k)
+    os.replace(state + '.tmp', state)
+    for k in dropped:
+        old = k if os.path.isabs(k) else os.path.join(d, k)
+        for path in [old + '.index'] + glob.glob(glob.escape(old) + '.data-?????-of-?????'):
+            if os.path.exists(path):
+                os.remove(path)
 
 
-def latest_checkpoint(ckpt_dir):
+def latest_checkpoint(ckpt_dir, scan=False):
     """tf.train.latest_checkpoint(dir): the `model_checkpoint_path` of the `checkpoint` state file, if that
-    prefix exists; None otherwise."""
+    prefix exists; None otherwise.  scan=True: when the state file is missing, or names a prefix that is not there
+    (a copy of the directory without it; a run killed between writing a bundle and the state file), fall back to the
+    highest-numbered complete `model.ckpt-<N>` bundle of the directory instead of silently starting from step 0."""
     state = os.path.join(ckpt_dir, 'checkpoint')
-    if not os.path.exists(state):
+    if os.path.exists(state):
+        for line in open(state):
+            line = line.strip()
+            if line.startswith('model_checkpoint_path:'):
+                name = line.split(':', 1)[1].strip().strip('"')
+                prefix = name if os.path.isabs(name) else os.path.join(ckpt_dir, name)
+                if is_checkpoint_prefix(prefix):
+                    return prefix
+                break
+    return newest_bundle(ckpt_dir) if scan else None
+
+
+def newest_bundle(ckpt_dir, stem='model.ckpt-'):
+    """The complete bundle `<stem><N>` with the largest N in `ckpt_dir` (index and every data shard present)."""
+    best = None
+    if not (ckpt_dir and os.path.isdir(ckpt_dir)):
         return None
-    for line in open(state):
-        line = line.strip()
-        if line.startswith('model_checkpoint_path:'):
-            name = line.split(':', 1)[1].strip().strip('"')
-            prefix = name if os.path.isabs(name) else os.path.join(ckpt_dir, name)
-            return prefix if is_checkpoint_prefix(prefix) else None
-    return None
+    for name in os.listdir(ckpt_dir):
+        if not (name.startswith(stem) and name.endswith('.index')):
+            continue
+        try:
+            n = int(name[len(stem):-len('.index')])
+        except ValueError:
+            continue
+        prefix = os.path.join(ckpt_dir, name[:-len('.index')])
+        shards = glob.glob(glob.escape(prefix) + '.data-?????-of-?????')
+        if shards and len(shards) == int(shards[0].rsplit('-', 1)[1]) and (best is None or n > best[0]):
+            best = (n, prefix)
+    return best[1] if best else None
 
 
 def is_checkpoint_prefix(path):

@@ -80,3 +80,59 @@ def test_shard_rejects_ragged_batches():
     from ml_super_resolution_amd import dist as srx_dist
     with pytest.raises(ValueError):
         srx_dist.shard(torch.zeros(5, 2), 0, 2)
+
+
+def _flat_worker(rank, world, port, out_dir):
+    """dist.attach_flat on the real EnetModel object (host tensors, no kernels): rank 0 resumed from a checkpoint
+    (step 6, slots), rank 1 did not (step 5, other weights, no slots) -- or the other way round for `case` 1."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ml_super_resolution_amd import dist as srx_dist
+    from ml_super_resolution_amd.enet import model_enet, model_vgg
+    srx_dist.init_process_group(rank, world, backend='gloo')
+    for case in (0, 1):
+        m = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0, width=4), device='cpu', seed=10 * rank + case,
+                                 d_width=4, image_size=32, dense_units=8)
+        G, P = m.generator, m.discriminator.pool
+        has_state = (rank == 0) == (case == 0)
+        if has_state:
+            gen = torch.Generator().manual_seed(5 + rank)
+            m.global_step = 6 + rank
+            m.g_state.update({'t': 6 + rank, 'm': torch.randn(G.params.shape, generator=gen), 'v': torch.rand(G.params.shape, generator=gen)})
+            P.t = 2 + rank
+            P.opt_m, P.opt_v = torch.randn(P.params.shape, generator=gen), torch.rand(P.params.shape, generator=gen)
+        else:
+            m.global_step = 5
+        srx_dist.attach_flat(m, world)
+        out = {'g': G.params.numpy(), 'd': P.params.numpy(), 'step': np.int64(m.global_step), 'has_g': np.int64(bool(m.g_state)),
+               'has_d': np.int64(P.opt_m is not None), 'd_t': np.int64(P.t)}
+        if m.g_state:
+            out.update(g_t=np.int64(m.g_state['t']), g_m=m.g_state['m'].numpy(), g_v=m.g_state['v'].numpy(), d_m=P.opt_m.numpy(), d_v=P.opt_v.numpy())
+        # the hooks average over the ranks
+        g = torch.full((8,), float(rank + 1))
+        m.grad_hook_g(g)
+        m.grad_hook_d(g)
+        out['hooked'] = g.numpy()
+        np.savez(os.path.join(out_dir, 'flat%d_%d.npz' % (case, rank)), **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_attach_flat_levels_step_counts_and_adam_slots(tmp_path):
+    """ADVICE r2 (dist.py:115): EnhanceNet's `global_step` decides which steps run d_trainer
+    (enet/enet/experiment_train.py:112); ranks that disagree issue different collectives.  Everything comes from rank 0 --
+    also when rank 0 is the one WITHOUT optimizer state (the other rank's slots are dropped)."""
+    port = _free_port()
+    mp.spawn(_flat_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / 'flat0_0.npz'), np.load(tmp_path / 'flat0_1.npz')
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert (int(a['step']), int(a['g_t']), int(a['d_t']), int(a['has_g']), int(a['has_d'])) == (6, 6, 2, 1, 1)
+    np.testing.assert_array_equal(a['hooked'], np.full(8, 1.5, np.float32))          # mean of 1 and 2, reduced twice: still 1.5
+    a, b = np.load(tmp_path / 'flat1_0.npz'), np.load(tmp_path / 'flat1_1.npz')
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert (int(b['step']), int(b['has_g']), int(b['has_d']), int(b['d_t'])) == (5, 0, 0, 0)

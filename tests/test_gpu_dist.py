@@ -123,6 +123,74 @@ def test_enet_two_ranks_equal_single_process(tmp_path):
         assert np.abs(r0[pk] - one[pk])[big].max() <= 2e-6 * max(np.abs(one[pk]).max(), 1.0)
 
 
+def test_enet_two_ranks_level_a_resumed_rank_zero(tmp_path):
+    """dist.attach_flat: rank 0 comes out of a checkpoint (global_step 6 -- a d_trainer step of the schedule,
+    enet/enet/experiment_train.py:112 --, both optimizers' slots and step counts), rank 1 found none and sits at step 5
+    without slots.  After attach_flat both hold rank 0's state; one d run + one g run later the replicas are
+    bit-identical in parameters, slots and counts, and agree with ONE process resumed from the same state."""
+    d2 = tmp_path / 'w2'
+    d2.mkdir()
+    r0, r1 = _run_ranks(d2, 2, ['enet_resumed', 4])
+    d1 = tmp_path / 'w1'
+    d1.mkdir()
+    one = _single(d1, ['enet_resumed', 4])
+    for key in ('g_params', 'd_params', 'g_grad', 'd_grad', 'g_m', 'g_v', 'd_m', 'd_v'):
+        np.testing.assert_array_equal(r0[key], r1[key], err_msg=key)
+    for r in (r0, r1, one):
+        assert (int(r['global_step']), int(r['g_t']), int(r['d_t'])) == (7, 7, 3)
+    assert int(r0['n_hook_calls']) == 2 and float(r0['allreduce_ms']) > 0
+    for key in ('g_grad', 'd_grad'):
+        assert np.abs(r0[key] - one[key]).max() <= 5e-5 * np.abs(one[key]).max(), key
+    for key in ('g_m', 'd_m', 'g_v', 'd_v'):
+        assert np.abs(r0[key] - one[key]).max() <= 1e-5 * np.abs(one[key]).max(), key
+    # (started from one's slots: a rank that had begun with EMPTY slots would be off by the whole first moment)
+    assert np.abs(one['g_m']).max() > 1e-4
+
+
+def _group_of_one(out_dir, args):
+    """ONE fresh child process that forms a world-size-1 process group with the backend dist.py picks on a GPU box:
+    `nccl` = RCCL.  Runs the branches the gloo rehearsals cannot: all_reduce(AVG) on a device buffer, the device-side
+    broadcasts of attach() / attach_flat(), destroy_process_group."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SRX_DIST_BACKEND')}
+    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               SRX_TEST_GROUP_OF_ONE='1', SRX_TEST_EXPECT_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, WORKER, str(out_dir)] + [str(a) for a in args], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors='replace')[-3000:]
+    return np.load(os.path.join(str(out_dir), 'rank0.npz'))
+
+
+def test_rccl_group_of_one_vdsr(tmp_path):
+    """RCCL initialised by THIS code on the one GPU of the box: init_process_group('nccl'), dist.attach(timed=True) on
+    the real VdsrModel, two train steps through all_reduce(AVG) of the flat gradient buffer -- bit-equal to the
+    hook-less run (the average over one rank is the identity), hook timed, group destroyed cleanly."""
+    args = [1, 2, 6, 8, 5e-5]
+    dn = tmp_path / 'nccl'
+    dn.mkdir()
+    r = _group_of_one(dn, args)
+    d1 = tmp_path / 'plain'
+    d1.mkdir()
+    one = _single(d1, args)
+    for key in ('params', 'opt_m', 'opt_v', 'first_grad', 'losses'):
+        np.testing.assert_array_equal(r[key], one[key], err_msg=key)
+    assert int(r['n_hook_calls']) == 2 and float(r['allreduce_ms']) > 0.0 and int(r['global_step']) == 2
+
+
+def test_rccl_group_of_one_enet(tmp_path):
+    """The same for dist.attach_flat (EnhanceNet's two flat buffers), from a resumed state: device-side broadcast of the
+    counts and of both pairs of Adam slots, one all_reduce(AVG) per trainer run."""
+    dn = tmp_path / 'nccl'
+    dn.mkdir()
+    r = _group_of_one(dn, ['enet_resumed', 2])
+    d1 = tmp_path / 'plain'
+    d1.mkdir()
+    one = _single(d1, ['enet_resumed', 2])
+    for key in ('g_params', 'd_params', 'g_grad', 'd_grad', 'g_m', 'g_v', 'd_m', 'd_v', 'a_loss', 'g_loss_all'):
+        np.testing.assert_array_equal(r[key], one[key], err_msg=key)
+    assert int(r['n_hook_calls']) == 2 and float(r['allreduce_ms']) > 0.0
+    assert (int(r['global_step']), int(r['g_t']), int(r['d_t'])) == (7, 7, 3)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two fresh ranks (gloo on a
     one-GPU box), rank 0 prints ONE JSON line with the contract's keys."""

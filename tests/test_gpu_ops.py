@@ -1,5 +1,7 @@
 """GPU parity tests of the C-ABI ops (libsrx.so) against the CPU oracle and the committed
 golden vectors.  Tolerance: 1e-3 relative fp32 (north_star); the sub-pixel maps are bit-exact."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -129,7 +131,7 @@ SHAPES = [
 @pytest.mark.parametrize('shape', SHAPES, ids=['%dx%dx%d_k%d_%d-%d_%s' % s[:7] for s in SHAPES])
 def test_conv_fwd_bwd_vs_oracle(shape, ops, conv_path):
     N, H, W, k, cin, cout, pad, act = shape
-    rng = np.random.default_rng(abs(hash(shape)) % (1 << 31))
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))       # (hash() of a tuple with strings changes per process)
     x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
     w = rng.normal(0, 1.0 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, (cout,)).astype(np.float32)

@@ -131,3 +131,82 @@ def test_blocked_kernel_layout_and_enet_variable_names():
     assert [c for _, c, _ in model_enet.discriminator_layers()] == [32, 32, 64, 64, 128, 128, 256, 256, 512, 512]
     # truncated_normal(0.02): nothing beyond two sigma
     assert float(v['d_/conv2d_9/kernel'].abs().max()) <= 0.04 + 1e-6
+
+
+def _small_enet(seed=0):
+    from ml_super_resolution_amd.enet import model_enet, model_vgg
+    return model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0, width=4), device='cpu', seed=seed, d_width=4,
+                                image_size=32, dense_units=8)
+
+
+@pytest.mark.parametrize('g_steps', [999, 5000, 100000])
+def test_enet_resume_step_counts_survive_beta_power_underflow(tmp_path, g_steps):
+    """enet/enet/experiment_train.py:99-160 saves at step % 1000 == 999; float32 0.9 ** 1000 is 0.0 (TensorFlow would
+    store the same), so the Adam step counts must not be recovered by inverting beta1_power."""
+    from ml_super_resolution_amd import tf_bundle
+    m = _small_enet()
+    G, P = m.generator, m.discriminator.pool
+    gen = torch.Generator().manual_seed(1)
+    m.global_step = g_steps
+    m.g_state.update({'t': g_steps, 'm': torch.randn(G.params.shape, generator=gen), 'v': torch.rand(G.params.shape, generator=gen)})
+    P.t = (g_steps + 2) // 3 + 5                  # (not what the schedule would give: must come back as stored)
+    P.opt_m, P.opt_v = torch.randn(P.params.shape, generator=gen), torch.rand(P.params.shape, generator=gen)
+    tensors = m.tf_checkpoint_tensors()
+    if g_steps >= 999:
+        assert float(tensors['beta1_power']) == 0.0       # the value that used to raise OverflowError on resume
+    prefix = str(tmp_path / ('model.ckpt-%d' % g_steps))
+    m.save_tf_checkpoint(prefix)
+    other = _small_enet(seed=5)
+    other.load_tf_checkpoint(prefix)
+    assert other.global_step == g_steps and other.g_state['t'] == g_steps and other.discriminator.pool.t == P.t
+    for (name, val, am, av, _, _), (_, val2, bm, bv, _, _) in zip(m._named_buffers(), other._named_buffers()):
+        # (views of the variables: the flat buffers' alignment padding belongs to no variable)
+        assert torch.equal(val, val2) and torch.equal(am, bm) and torch.equal(av, bv), name
+    # a TensorFlow-written file has no explicit count: beta2_power_1 while it is a normal float, the schedule after that
+    del tensors['srx/d_trainer_steps']
+    prefix2 = str(tmp_path / 'foreign.ckpt')
+    tf_bundle.save_checkpoint(prefix2, tensors)
+    third = _small_enet(seed=6)
+    third.load_tf_checkpoint(prefix2)
+    assert third.g_state['t'] == g_steps
+    if 0.999 ** (P.t + 1) > 1.2e-38:
+        assert third.discriminator.pool.t == P.t
+    else:
+        assert third.discriminator.pool.t == (g_steps + 2) // 3
+
+
+def test_enet_d_steps_guards():
+    from ml_super_resolution_amd.enet.model_enet import EnetModel
+    f = EnetModel._d_steps_from_checkpoint
+    for t in (0, 1, 333, 1667, 20000, 80000):
+        assert f({'beta2_power_1': np.float32(0.999 ** (t + 1))}, 0) == t
+    for bad in (np.float32(0.0), np.float32(1e-42), np.float32('nan'), np.float32(1.0)):
+        assert f({'beta2_power_1': bad, 'beta1_power_1': np.float32(0.0)}, 2999) == 1000
+    assert f({}, 10) == 4
+    assert f({'srx/d_trainer_steps': np.int64(77), 'beta2_power_1': np.float32(0.5)}, 10) == 77
+
+
+def test_load_vgg_weights_reads_the_keras_named_npz(tmp_path):
+    """enet/enet/model_vgg.py:39-62: the .npz holds `<layer>_W_1:0` / `<layer>_b_1:0`; scope = first 12 characters,
+    constant name = the name without ':0'.  The path a user with the real file takes: npz -> load_vgg_weights -> Vgg19."""
+    from ml_super_resolution_amd.enet import model_vgg
+    w = model_vgg.random_vgg_weights(3, width=8)
+    arrays = {}
+    for layer, d in w.items():
+        for const, a in d.items():
+            arrays[const + ':0'] = a
+    path = str(tmp_path / 'vgg19_weights_tf_dim_ordering_tf_kernels_notop.npz')
+    np.savez(path, **arrays)
+    got = model_vgg.load_vgg_weights(path)
+    assert sorted(got) == sorted(n for n in model_vgg.LAYER_NAMES if 'conv' in n) and len(got) == 16
+    assert sorted(got['block3_conv4']) == ['block3_conv4_W_1', 'block3_conv4_b_1']
+    net = model_vgg.Vgg19(got, device='cpu')
+    for layer in w:
+        np.testing.assert_array_equal(net.layers[layer].kernel_hwio().numpy(), w[layer][layer + '_W_1'])
+        np.testing.assert_array_equal(net.layers[layer].b.numpy(), w[layer][layer + '_b_1'])
+    assert model_vgg.load_vgg_weights(str(tmp_path / 'missing.npz')) == {}          # :45-46
+    from ml_super_resolution_amd import graph
+    from ml_super_resolution_amd.enet import model_enet
+    with pytest.raises(ValueError, match='VGG-19 weights not found'):
+        model_enet.build_enet(graph.placeholder(name='sd'), graph.placeholder(name='bq'), graph.placeholder(name='hd'),
+                              'pat', str(tmp_path / 'missing.npz'), device='cpu')

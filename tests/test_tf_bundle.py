@@ -242,3 +242,38 @@ def test_unsupported_bundle_features_are_refused_loudly(tmp_path):
     open(prefix + '.data-00000-of-00001', 'wb').write(b'\\0' * 8)
     with pytest.raises(ValueError, match='partitioned'):
         tb.load_checkpoint(prefix)
+
+
+def test_saver_housekeeping_atomic_writes_max_to_keep_and_scan_fallback(tmp_path):
+    """tf.train.Saver() keeps 5 checkpoints and tf.train.latest_checkpoint reads the state file
+    (enet/enet/experiment_train.py:96-117).  A bundle is complete once its `.index` exists (temporary names until
+    then); without a usable state file the newest complete `model.ckpt-N` is found instead of restarting at step 0."""
+    from ml_super_resolution_amd import tf_bundle as B
+    d = tmp_path / 'ckpt'
+    d.mkdir()
+    for n in range(999, 8999, 1000):
+        prefix = str(d / ('model.ckpt-%d' % n))
+        B.save_checkpoint(prefix, {'global_step': np.asarray(n, np.int64), 'w': np.full((3,), n, np.float32)})
+        B.update_checkpoint_state(prefix)
+    names = sorted(os.listdir(str(d)))
+    assert not [n for n in names if n.endswith('.tmp')]
+    kept = [3999, 4999, 5999, 6999, 7999]
+    assert sorted(n for n in names if n.endswith('.index')) == ['model.ckpt-%d.index' % n for n in kept]
+    assert len([n for n in names if '.data-' in n]) == 5
+    text = open(str(d / 'checkpoint')).read().splitlines()
+    assert text == ['model_checkpoint_path: "model.ckpt-7999"'] + ['all_model_checkpoint_paths: "model.ckpt-%d"' % n for n in kept]
+    assert B.latest_checkpoint(str(d)) == str(d / 'model.ckpt-7999')
+    # the state file is gone (a copied directory): plain lookup finds nothing, the scan finds the newest bundle
+    os.remove(str(d / 'checkpoint'))
+    assert B.latest_checkpoint(str(d)) is None
+    assert B.latest_checkpoint(str(d), scan=True) == str(d / 'model.ckpt-7999')
+    # a save that was killed half way: data written, index still under its temporary name -> not a checkpoint
+    open(str(d / 'model.ckpt-8999.data-00000-of-00001'), 'wb').write(b'x' * 20)
+    open(str(d / 'model.ckpt-8999.index.tmp'), 'wb').write(b'y')
+    assert B.latest_checkpoint(str(d), scan=True) == str(d / 'model.ckpt-7999')
+    # a state file that names a prefix which is not there
+    open(str(d / 'checkpoint'), 'w').write('model_checkpoint_path: "model.ckpt-8999"\n')
+    assert B.latest_checkpoint(str(d)) is None
+    assert B.latest_checkpoint(str(d), scan=True) == str(d / 'model.ckpt-7999')
+    assert int(B.load_checkpoint(B.latest_checkpoint(str(d), scan=True))['global_step']) == 7999
+    assert B.newest_bundle(str(tmp_path / 'nothing')) is None
