@@ -160,6 +160,12 @@ int srx_act_bwd(const float* dy, const float* y, float* dpre, size_t numel, int 
 int srx_depth_to_space(const float* in, float* out, int N, int H, int W, int C, int r,
                        srx_stream_t stream);
 
+/* Measurement aid, not an operator of the path: a plain streaming copy (nontemporal 16-byte loads and stores, the
+ * launch shape of the sub-pixel kernels).  bench.py times it on the sub-pixel map's own buffers: what a kernel that
+ * only moves these bytes reaches at this transfer size is the ceiling the map is compared with
+ * (`subpixel.copy_ceiling_gbps`).  in / out 16-byte aligned, bytes a multiple of 16.  No reference counterpart. */
+int srx_stream_copy(const void* in, void* out, size_t bytes, srx_stream_t stream);
+
 /* ESPCN inference in ONE launch (espcn/espcn/model_espcn.py:117-134 + espcn/espcn/experiment_test.py:171-177):
  *   t1 = tanh(conv5x5(x; 3->64) + b1), t2 = tanh(conv3x3(t1; 64->32) + b2), y = conv3x3(t2; 32->3 r^2) + b3 (all SAME),
  *   hr[n, h r + dy, w r + dx, c] = y[n, h, w, (dy r + dx) 3 + c]

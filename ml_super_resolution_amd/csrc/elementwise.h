@@ -5,7 +5,12 @@
 namespace srx {
 constexpr int kReduceBlocks = 1024;  // partial slots a reduction may use (srx_reduce_scratch_bytes)
 
-hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse, hipStream_t s);
+// chunk_kb: a chunk grows while twice its size stays within this many KiB; db: two LDS buffers (software pipeline);
+// grid: cap of the persistent grid
+struct SubpixelTune { int chunk_kb, db, grid; };
+hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
+                           const SubpixelTune& tune, hipStream_t s);
+hipError_t launch_stream_copy(const float* in, float* out, size_t bytes, hipStream_t s);
 hipError_t launch_mse(const float* pred, const float* target, size_t n, float inv, float* loss, int accumulate,
                       float* dpred, float* scratch, hipStream_t s);
 hipError_t launch_l2(const float* w, const float* mask, size_t n, float scale, float* loss, int accumulate, float* scratch,

@@ -44,11 +44,44 @@ __device__ __forceinline__ int s2d_src(int oo, int W, int rC, int r, float inv_r
 // chunk = RB blocks (chunk_floats = RB*B, a multiple of 4).  Every chunk undergoes the SAME
 // permutation, so a thread computes the LDS gather indices of its (at most KMAX) output float4s once
 // and then only moves data: coalesced 16-B loads -> LDS -> 4 scalar LDS reads -> coalesced 16-B store.
-template <bool INVERSE, int KMAX>
+//
+// Software pipeline (DB = two LDS buffers): the loads of chunk c+1 are issued right after chunk c has been
+// written to LDS, i.e. BEFORE chunk c is gathered and stored, so every wave keeps a chunk of reads in flight
+// while it works through LDS; one barrier per chunk (a thread that writes buffer p for chunk c has passed the
+// barrier of chunk c-1, which every thread reaches only after its gather of chunk c-2 from the same buffer).
+// The first chunk's loads go out before the index computation (~30 integer divisions per thread by
+// reciprocal multiplication), which then runs under the memory latency instead of in front of it.
+// The barrier is the raw s_barrier behind an LDS-only wait: __syncthreads() would also drain the
+// vector-memory queue, i.e. wait for the loads just issued.
+//
+// Gather without the 4-way bank conflict of "lane l reads output floats 4l+e in round e" (ds_read_b32 banks
+// are (a/4) % 32 per 32-lane half: the lanes of a round sit 4 floats apart and hit 8 banks): in round e lane l
+// reads element (e + l/8) % 4 of its float4 instead, so the four 8-lane groups of a half start on banks
+// 0,1,2,3 (+ the permutation's own offsets), and the float4 is put back in order with two select stages.
+template <bool INVERSE, int KMAX, bool DB>
 __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            size_t total, int B, int chunk_floats, int W, int rC,
                                                            int r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c4 = chunk_floats >> 2;
+    const size_t stride = (size_t)gridDim.x * chunk_floats;
+    size_t c0 = (size_t)blockIdx.x * chunk_floats;
+    if (c0 >= total) return;
+    auto chunk_len = [&](size_t at) -> int {
+        return (int)((total - at < (size_t)chunk_floats) ? (total - at) : (size_t)chunk_floats);
+    };
+    f32x4 v[KMAX];
+    auto issue_loads = [&](size_t at, int n4) {
+        const f32x4* gin = reinterpret_cast<const f32x4*>(in + at);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) v[k] = __builtin_nontemporal_load(gin + i);   // streamed once: keep it out of L2
+        }
+    };
+    int n = chunk_len(c0);
+    issue_loads(c0, n >> 2);
+
     const float inv_B = 1.0f / (float)B;
     const float inv_a = INVERSE ? 1.0f / (float)(r * rC) : 1.0f / (float)(W * rC);
     const float inv_rC = 1.0f / (float)rC;
@@ -59,45 +92,82 @@ __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restri
         const int oo = o - blk * B;
         return blk * B + (INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC));
     };
-    const int c4 = chunk_floats >> 2;
+    const int rot = (threadIdx.x >> 3) & 3;
     int sidx[KMAX][4];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int i = k * 256 + threadIdx.x;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sidx[k][e] = (i < c4) ? src_of(4 * i + e) : 0;
+        for (int e = 0; e < 4; ++e) sidx[k][e] = (i < c4) ? src_of(4 * i + ((e + rot) & 3)) : 0;
     }
-    for (size_t c0 = (size_t)blockIdx.x * chunk_floats; c0 < total; c0 += (size_t)gridDim.x * chunk_floats) {
-        const int n = (int)((total - c0 < (size_t)chunk_floats) ? (total - c0) : (size_t)chunk_floats);
+    const bool r1 = rot & 1, r2 = rot & 2;
+    int p = 0;
+    for (;;) {
         const int n4 = n >> 2;
-        const f32x4* gin = reinterpret_cast<const f32x4*>(in + c0);
+        float* buf = lds + (DB ? p * chunk_floats : 0);
+        if (!DB) lds_barrier();   // single buffer: the previous chunk's gathers are done
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) reinterpret_cast<f32x4*>(buf)[i] = v[k];
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) buf[i] = in[c0 + i];
+        const size_t next = c0 + stride;
+        const bool more = next < total;
+        const int nn = more ? chunk_len(next) : 0;
+        if (more) issue_loads(next, nn >> 2);
+        lds_barrier();
         f32x4* gout = reinterpret_cast<f32x4*>(out + c0);
-        f32x4 v[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int i = k * 256 + threadIdx.x;
-            if (i < n4) v[k] = __builtin_nontemporal_load(gin + i);   // streamed once: keep it out of L2
-        }
-        __syncthreads();   // previous chunk's gathers are done
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int i = k * 256 + threadIdx.x;
-            if (i < n4) reinterpret_cast<f32x4*>(lds)[i] = v[k];
-        }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) lds[i] = in[c0 + i];
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int i = k * 256 + threadIdx.x;
             if (i < n4) {
+                float a0 = buf[sidx[k][0]], a1 = buf[sidx[k][1]], a2 = buf[sidx[k][2]], a3 = buf[sidx[k][3]];
+                // a_e = element (e + rot) % 4  ->  element j = a_{(j - rot) % 4}: rotate right by rot
+                float b0 = r1 ? a3 : a0, b1 = r1 ? a0 : a1, b2 = r1 ? a1 : a2, b3 = r1 ? a2 : a3;
                 f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = lds[sidx[k][e]];
+                o[0] = r2 ? b2 : b0; o[1] = r2 ? b3 : b1; o[2] = r2 ? b0 : b2; o[3] = r2 ? b1 : b3;
                 __builtin_nontemporal_store(o, gout + i);
             }
         }
-        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) out[c0 + o] = lds[src_of(o)];
+        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) out[c0 + o] = buf[src_of(o)];
+        if (!more) break;
+        c0 = next;
+        n = nn;
+        p ^= 1;
     }
+}
+
+// What a plain streaming copy of the same bytes reaches with the same launch shape (persistent workgroups, KMAX
+// nontemporal 16-B loads in flight per thread, nontemporal stores): the ceiling the sub-pixel map is measured
+// against (bench.py `subpixel.copy_ceiling_gbps`).
+template <int KMAX>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t n4) {
+    const size_t per = (size_t)KMAX * 256;
+    for (size_t base = (size_t)blockIdx.x * per; base < n4; base += (size_t)gridDim.x * per) {
+        f32x4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            if (i < n4) v[k] = __builtin_nontemporal_load(in + i);
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            if (i < n4) __builtin_nontemporal_store(v[k], out + i);
+        }
+    }
+}
+
+hipError_t launch_stream_copy(const float* in, float* out, size_t bytes, hipStream_t s) {
+    const size_t n4 = bytes / 16;
+    if (n4 == 0) return hipSuccess;
+    const size_t per = 8 * 256;
+    size_t nb = (n4 + per - 1) / per;
+    const int grid = (int)(nb < 2048 ? nb : 2048);
+    hipLaunchKernelGGL(stream_copy_kernel<8>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const f32x4*>(in),
+                       reinterpret_cast<f32x4*>(out), n4);
+    return hipGetLastError();
 }
 
 // Fallback for rows too long for LDS: direct gather (reads stay inside one B-float block).
@@ -115,7 +185,7 @@ __global__ __launch_bounds__(256) void subpixel_direct_kernel(const float* __res
 }
 
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
-                           hipStream_t s) {
+                           const SubpixelTune& kn, hipStream_t s) {
     const int rC = r * C;
     const size_t B = (size_t)W * r * rC;
     const size_t total = (size_t)N * H * B;
@@ -125,23 +195,28 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
     size_t RB = 4;
     if (B % 4 == 0) RB = 1; else if (B % 2 == 0) RB = 2;
     if (RB * B * 4 <= lds_cap && B < (1u << 20)) {
-        while (2 * RB * B * 4 <= 24 * 1024) RB *= 2;   // ~16-24 KiB chunks: several workgroups per CU
+        const size_t target = (size_t)kn.chunk_kb * 1024;
+        while (2 * RB * B * 4 <= target) RB *= 2;   // ~16-24 KiB chunks: several workgroups per CU
         const int chunk = (int)(RB * B);
         size_t nchunks = (total + chunk - 1) / chunk;
+        // two LDS buffers (loads of the next chunk in flight during the gather) while four workgroups still share a CU
+        const bool db = kn.db && (size_t)chunk * 8 <= 40 * 1024;
         // persistent workgroups: the index precomputation is paid once per workgroup
-        int grid = (int)(nchunks < 1024 ? nchunks : 1024);
+        const size_t cap = (size_t)(kn.grid > 0 ? kn.grid : 1024);
+        int grid = (int)(nchunks < cap ? nchunks : cap);
         const int kneed = (chunk / 4 + 255) / 256;
+        const size_t lds = (size_t)chunk * 4 * (db ? 2 : 1);
+#define SRX_SUBPIXEL_LAUNCH2(INV, K, DBUF)                                                                      \
+        hipLaunchKernelGGL((subpixel_lds_kernel<INV, K, DBUF>), dim3(grid), dim3(256), lds, s, in, out, total,  \
+                           (int)B, chunk, W, rC, r);
 #define SRX_SUBPIXEL_LAUNCH(K)                                                                                   \
-        if (inverse)                                                                                             \
-            hipLaunchKernelGGL((subpixel_lds_kernel<true, K>), dim3(grid), dim3(256), chunk * 4, s, in, out,    \
-                               total, (int)B, chunk, W, rC, r);                                                  \
-        else                                                                                                     \
-            hipLaunchKernelGGL((subpixel_lds_kernel<false, K>), dim3(grid), dim3(256), chunk * 4, s, in, out,   \
-                               total, (int)B, chunk, W, rC, r);
+        if (inverse) { if (db) { SRX_SUBPIXEL_LAUNCH2(true, K, true) } else { SRX_SUBPIXEL_LAUNCH2(true, K, false) } }    \
+        else { if (db) { SRX_SUBPIXEL_LAUNCH2(false, K, true) } else { SRX_SUBPIXEL_LAUNCH2(false, K, false) } }
         if (kneed <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
         else if (kneed <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
         else { SRX_SUBPIXEL_LAUNCH(12) }
 #undef SRX_SUBPIXEL_LAUNCH
+#undef SRX_SUBPIXEL_LAUNCH2
     } else {
         if (B >= (1u << 22)) return hipErrorInvalidValue;
         size_t nb = (total + 255) / 256;

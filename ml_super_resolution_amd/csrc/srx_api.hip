@@ -21,6 +21,7 @@ thread_local char g_err[512] = "";
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
     int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe;
+    int subpixel_chunk_kb, subpixel_db, subpixel_grid;
     unsigned long long* trace;
     int dbg;
 };
@@ -37,6 +38,9 @@ Knobs read_knobs() {
     k.stagger = env_int("SRX_STAGGER", -1);
     k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
+    k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
+    k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
+    k.subpixel_grid = env_int("SRX_SUBPIXEL_GRID", 0);
     k.trace = nullptr;
     k.dbg = 0;
 #ifdef SRX_TRACE
@@ -644,7 +648,16 @@ static int subpixel(const float* in, float* out, int N, int H, int W, int C, int
     if (!aligned16(in) || !aligned16(out)) return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     if (in == out) return fail(SRX_ERR_BAD_ARG, "sub-pixel map cannot run in place");
     if (N == 0 || H == 0 || W == 0) return SRX_OK;
-    SRX_CHECK_LAUNCH(launch_subpixel(in, out, N, H, W, C, r, inv, (hipStream_t)stream), "sub-pixel map");
+    const SubpixelTune tune = {knobs().subpixel_chunk_kb, knobs().subpixel_db,
+                               knobs().subpixel_grid > 0 ? knobs().subpixel_grid : 4 * cu_count()};
+    SRX_CHECK_LAUNCH(launch_subpixel(in, out, N, H, W, C, r, inv, tune, (hipStream_t)stream), "sub-pixel map");
+}
+
+int srx_stream_copy(const void* in, void* out, size_t bytes, srx_stream_t stream) {
+    if (!in || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (!aligned16(in) || !aligned16(out) || (bytes & 15u)) return fail(SRX_ERR_ALIGN, "stream copy moves whole 16-byte vectors");
+    if (bytes == 0) return SRX_OK;
+    SRX_CHECK_LAUNCH(launch_stream_copy((const float*)in, (float*)out, bytes, (hipStream_t)stream), "stream copy");
 }
 
 int srx_depth_to_space(const float* in, float* out, int N, int H, int W, int C, int r, srx_stream_t stream) {

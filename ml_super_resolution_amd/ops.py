@@ -186,6 +186,15 @@ def space_to_depth(x, r, out=None):
     return out
 
 
+def stream_copy(src, dst):
+    """Plain streaming copy on the library's own copy kernel (a measurement aid: the ceiling of a byte-moving kernel)."""
+    _chk(src, 'src'); _chk(dst, 'dst')
+    if src.numel() != dst.numel():
+        raise ValueError('stream_copy: sizes differ')
+    check(lib().srx_stream_copy(_ptr(src), _ptr(dst), src.numel() * 4, _stream()), 'srx_stream_copy')
+    return dst
+
+
 def mse_fwd_bwd(pred, target, loss_out, inv_numel=None, accumulate=False, dpred=None, want_grad=True):
     """loss_out (+)= sum((pred-target)^2)*inv_numel; returns dpred = 2*(pred-target)*inv_numel."""
     _chk(pred, 'pred'); _chk(target, 'target')
