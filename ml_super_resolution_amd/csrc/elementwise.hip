@@ -45,96 +45,315 @@ __device__ __forceinline__ int s2d_src(int oo, int W, int rC, int r, float inv_r
 // permutation, so a thread computes the LDS gather indices of its (at most KMAX) output float4s once
 // and then only moves data: coalesced 16-B loads -> LDS -> 4 scalar LDS reads -> coalesced 16-B store.
 //
-// Software pipeline (DB = two LDS buffers): the loads of chunk c+1 are issued right after chunk c has been
-// written to LDS, i.e. BEFORE chunk c is gathered and stored, so every wave keeps a chunk of reads in flight
-// while it works through LDS; one barrier per chunk (a thread that writes buffer p for chunk c has passed the
-// barrier of chunk c-1, which every thread reaches only after its gather of chunk c-2 from the same buffer).
-// The first chunk's loads go out before the index computation (~30 integer divisions per thread by
-// reciprocal multiplication), which then runs under the memory latency instead of in front of it.
-// The barrier is the raw s_barrier behind an LDS-only wait: __syncthreads() would also drain the
-// vector-memory queue, i.e. wait for the loads just issued.
-//
 // Gather without the 4-way bank conflict of "lane l reads output floats 4l+e in round e" (ds_read_b32 banks
 // are (a/4) % 32 per 32-lane half: the lanes of a round sit 4 floats apart and hit 8 banks): in round e lane l
 // reads element (e + l/8) % 4 of its float4 instead, so the four 8-lane groups of a half start on banks
 // 0,1,2,3 (+ the permutation's own offsets), and the float4 is put back in order with two select stages.
-template <bool INVERSE, int KMAX, bool DB>
+__device__ __forceinline__ f32x4 unrotate4(float a0, float a1, float a2, float a3, bool r1, bool r2) {
+    // a_e = element (e + rot) % 4  ->  element j = a_{(j - rot) % 4}: rotate right by rot = r1 + 2 r2
+    const float b0 = r1 ? a3 : a0, b1 = r1 ? a0 : a1, b2 = r1 ? a1 : a2, b3 = r1 ? a2 : a3;
+    f32x4 o;
+    o[0] = r2 ? b2 : b0; o[1] = r2 ? b3 : b1; o[2] = r2 ? b0 : b2; o[3] = r2 ? b1 : b3;
+    return o;
+}
+
+// The permutation inside a chunk as index arithmetic.  With (N1, N2) = (r, W) for depth-to-space and (W, r) for its
+// inverse, an output position and its source are
+//   o   = blk*B + a*(N2*rC) + b*rC + j,      a < N1, b < N2, j < rC,  B = N1*N2*rC
+//   src = blk*B + b*(N1*rC) + a*rC + j
+// (the two inner digits swap places).  Divisions are multiplications by host-computed reciprocals
+// M = floor(2^32 / d) + 1 (exact for o * d < 2^32: o < 2^14 floats of LDS, d <= B < 2^14), every product fits 24 bits.
+struct SubpixelGeom {
+    int B, N1, N2, rC;          // block length, outer / inner digit ranges, run length
+    unsigned mA, mR, m1;        // reciprocals of N2*rC, rC, N1
+};
+
+inline SubpixelGeom subpixel_geom(int W, int rC, int r, bool inverse) {
+    SubpixelGeom g;
+    g.N1 = inverse ? W : r;
+    g.N2 = inverse ? r : W;
+    g.rC = rC;
+    g.B = W * r * rC;
+    auto magic = [](unsigned d) { return (unsigned)((1ull << 32) / d) + 1u; };   // (d = 1 is handled by the caller)
+    g.mA = magic((unsigned)(g.N2 * rC));
+    g.mR = magic((unsigned)rC);
+    g.m1 = magic((unsigned)g.N1);
+    return g;
+}
+
+struct SubpixelIndex {
+    SubpixelGeom g;
+    __device__ explicit SubpixelIndex(const SubpixelGeom& g_) : g(g_) {}
+    static __device__ __forceinline__ int divq(int o, int d, unsigned m) { return d == 1 ? o : (int)__umulhi((unsigned)o, m); }
+    // digits of position o
+    __device__ __forceinline__ void digits(int o, int& blk, int& a, int& b, int& j) const {
+        const int A = g.N2 * g.rC;
+        const int R = divq(o, A, g.mA);              // R = blk*N1 + a
+        const int rest = o - __mul24(R, A);
+        b = divq(rest, g.rC, g.mR);
+        j = rest - __mul24(b, g.rC);
+        blk = divq(R, g.N1, g.m1);
+        a = R - __mul24(blk, g.N1);
+    }
+    __device__ __forceinline__ int src(int blk, int a, int b, int j) const {
+        return __mul24(blk, g.B) + __mul24(b, __mul24(g.N1, g.rC)) + __mul24(a, g.rC) + j;
+    }
+    __device__ __forceinline__ int operator()(int o) const {
+        int blk, a, b, j;
+        digits(o, blk, a, b, j);
+        return src(blk, a, b, j);
+    }
+    // sources of the four consecutive positions o .. o+3: one digit decomposition, then
+    //  * runs of at least 4 (rC >= 4: every case of the reference, rC = 3r): at most ONE digit wrap inside the four, at
+    //    element rC - j; before it the source advances by 1 per element, from it on by 1 per element plus one jump whose
+    //    size depends on how far the carry goes (b, a, block);
+    //  * shorter runs: odometer steps.
+    __device__ __forceinline__ void four(int o, int (&out)[4]) const {
+        int blk, a, b, j;
+        digits(o, blk, a, b, j);
+        const int s0 = src(blk, a, b, j);
+        out[0] = s0;
+        // source increments when a digit wraps: j wraps -> b+1; b wraps -> a+1; a wraps -> blk+1
+        const int N1rC = __mul24(g.N1, g.rC);
+        const int dj = N1rC - (g.rC - 1);                                // (b+1, 0) - (b, rC-1)
+        const int db = g.rC - __mul24(g.N2 - 1, N1rC) - (g.rC - 1);        // (a+1, 0, 0) - (a, N2-1, rC-1)
+        const int da = g.B - __mul24(g.N1 - 1, g.rC) - __mul24(g.N2 - 1, N1rC) - (g.rC - 1);   // next block's first
+        if (g.rC >= 4) {   // (wave-uniform)
+            const bool wb = b == g.N2 - 1, wa = wb && a == g.N1 - 1;
+            const int jump = (wa ? da : (wb ? db : dj)) - 1;
+            const int at = g.rC - j;                                     // first element behind the wrap (>= 1)
+#pragma unroll
+            for (int e = 1; e < 4; ++e) out[e] = s0 + e + (e >= at ? jump : 0);
+            return;
+        }
+        int s = s0;
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+            ++j;
+            const bool wj = j == g.rC;
+            j = wj ? 0 : j;
+            b += wj;
+            const bool wb = b == g.N2;
+            b = wb ? 0 : b;
+            a += wb;
+            const bool wa = a == g.N1;
+            a = wa ? 0 : a;
+            s += wa ? da : (wb ? db : (wj ? dj : 1));
+            out[e] = s;
+        }
+    }
+    // the four sources of float4 slot i of a chunk of c4 float4s, in the rotated order of the gather: entry e is the
+    // source of element (e + rot) % 4; slots beyond the chunk get 0
+    __device__ __forceinline__ void rotated(int i, int c4, int rot, int (&out)[4]) const {
+        int t[4];
+        four(4 * i, t);
+        const bool r1 = rot & 1, r2 = rot & 2, in = i >= 0 && i < c4;
+        // entry e = t[(e + rot) % 4]: rotate left by rot
+        const int u0 = r1 ? t[1] : t[0], u1 = r1 ? t[2] : t[1], u2 = r1 ? t[3] : t[2], u3 = r1 ? t[0] : t[3];
+        out[0] = in ? (r2 ? u2 : u0) : 0;
+        out[1] = in ? (r2 ? u3 : u1) : 0;
+        out[2] = in ? (r2 ? u0 : u2) : 0;
+        out[3] = in ? (r2 ? u1 : u3) : 0;
+    }
+};
+
+// One LDS buffer, any chunk length (the last chunk of a tensor may be short and need not be a multiple of 4 floats):
+// rows too long for two buffers, and the ragged tail behind the pipelined kernel below.
+template <int KMAX>
 __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                           size_t total, int B, int chunk_floats, int W, int rC,
-                                                           int r) {
+                                                           size_t total, int chunk_floats, SubpixelGeom geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const SubpixelIndex src_of(geo);
     const int c4 = chunk_floats >> 2;
-    const size_t stride = (size_t)gridDim.x * chunk_floats;
-    size_t c0 = (size_t)blockIdx.x * chunk_floats;
-    if (c0 >= total) return;
-    auto chunk_len = [&](size_t at) -> int {
-        return (int)((total - at < (size_t)chunk_floats) ? (total - at) : (size_t)chunk_floats);
-    };
-    f32x4 v[KMAX];
-    auto issue_loads = [&](size_t at, int n4) {
-        const f32x4* gin = reinterpret_cast<const f32x4*>(in + at);
+    const int rot = (threadIdx.x >> 3) & 3;
+    const bool r1 = rot & 1, r2 = rot & 2;
+    int sidx[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) src_of.rotated(k * 256 + threadIdx.x, c4, rot, sidx[k]);
+    for (size_t c0 = (size_t)blockIdx.x * chunk_floats; c0 < total; c0 += (size_t)gridDim.x * chunk_floats) {
+        const int n = (int)((total - c0 < (size_t)chunk_floats) ? (total - c0) : (size_t)chunk_floats);
+        const int n4 = n >> 2;
+        const f32x4* gin = reinterpret_cast<const f32x4*>(in + c0);
+        f32x4* gout = reinterpret_cast<f32x4*>(out + c0);
+        f32x4 v[KMAX];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int i = k * 256 + threadIdx.x;
             if (i < n4) v[k] = __builtin_nontemporal_load(gin + i);   // streamed once: keep it out of L2
         }
-    };
-    int n = chunk_len(c0);
-    issue_loads(c0, n >> 2);
+        __syncthreads();   // previous chunk's gathers are done
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4) reinterpret_cast<f32x4*>(lds)[i] = v[k];
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) lds[i] = in[c0 + i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < n4)
+                __builtin_nontemporal_store(unrotate4(lds[sidx[k][0]], lds[sidx[k][1]], lds[sidx[k][2]], lds[sidx[k][3]], r1, r2),
+                                            gout + i);
+        }
+        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) out[c0 + o] = lds[src_of(o)];
+    }
+}
 
-    const float inv_B = 1.0f / (float)B;
-    const float inv_a = INVERSE ? 1.0f / (float)(r * rC) : 1.0f / (float)(W * rC);
-    const float inv_rC = 1.0f / (float)rC;
-    auto src_of = [&](int o) -> int {
-        int blk = (int)(((float)o + 0.5f) * inv_B);
-        blk -= (blk * B > o);
-        blk += ((blk + 1) * B <= o);
-        const int oo = o - blk * B;
-        return blk * B + (INVERSE ? s2d_src(oo, W, rC, r, inv_a, inv_rC) : d2s_src(oo, W, rC, r, inv_a, inv_rC));
+// The same map over FULL chunks (chunk_floats each; the launcher sends a ragged tail to the kernel above) with up to
+// DEPTH chunks of loads in flight per workgroup, held in registers.
+// What bounds a 93-MB transfer is how many of its bytes are in flight from the first microsecond on
+// (scripts/d2s_ubench.hip: a plain copy with 8 float4 per thread on 2048 workgroups -- every load of the tensor issued at
+// once -- takes 15.3 us; the same copy in two rounds of 4 float4 per thread 17.4 us; this kernel's chunk structure with
+// one chunk of loads per workgroup in flight and NO gather at all 18.0 us).  At [256,41,41,27] a persistent workgroup
+// owns 2-3 chunks: with DEPTH = 3 all of them are requested before the first one is touched.
+// * Two LDS buffers, one barrier per chunk (a thread that writes buffer p for chunk c has passed the barrier of chunk
+//   c-1, which every thread reaches only after its gather of chunk c-2 from the same buffer).
+// * No predicated memory instruction and no branch in a trip of DEPTH chunks: loads and stores are bounds-checked buffer
+//   operations (a float4 past the end of the chunk reads zeros / is dropped; a chunk at or beyond nfull has an EMPTY
+//   resource, so a trip's surplus steps move zeros through LDS and touch no memory), LDS writes of lanes beyond the
+//   chunk go to a per-thread dummy slot.  With every access unconditional the compiler's waits are COUNTED
+//   (s_waitcnt vmcnt(n)): an LDS write waits for its own chunk's loads only, not for younger loads and stores.
+//   (Per-lane `if (i < n4)` around each access makes them vmcnt(0).)  The dropped stores of the prologue put the
+//   vector-memory queue into the state every later trip finds at the loop top, so that the counts are the steady-state
+//   ones instead of the minimum over the two ways into the loop.
+// * The loads go out before the index computation, which then runs under the memory latency.
+// * The barrier is the raw s_barrier behind an LDS-only wait: __syncthreads() would also drain the vector-memory queue.
+// KMAX = ceil(chunk_floats / 4 / 256): only the last slot has lanes beyond the chunk.
+template <int KMAX, int DEPTH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))   // four workgroups per CU: <= 128 registers
+void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int nfull, int chunk_floats, SubpixelGeom geo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][chunk_floats] + [256][4] dummy slots
+    int c = blockIdx.x;
+    if (c >= nfull) return;
+    const int G = gridDim.x;
+    const int c4 = chunk_floats >> 2;
+    const unsigned chunk_bytes = (unsigned)chunk_floats * 4u;
+    const int lane_off = threadIdx.x * 16;
+    auto rsrc_at = [&](const float* base, int chunk) {
+        const bool ok = chunk < nfull;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)(ok ? chunk : 0) * chunk_floats), 0,
+                                                 ok ? chunk_bytes : 0u, 0x00020000);
     };
+    u32x4v v[DEPTH][KMAX];
+    auto issue = [&](u32x4v (&dst)[KMAX], int chunk) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_at(in, chunk);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2 /* nt */);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        issue(v[d], c + d * G);
+        const __amdgpu_buffer_rsrc_t rs = rsrc_at(out, nfull);   // empty: the stores are dropped
+        const u32x4v z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rs, lane_off + k * 4096, 0, 2);
+    }
+    const SubpixelIndex src_of(geo);
     const int rot = (threadIdx.x >> 3) & 3;
-    int sidx[KMAX][4];
+    const bool r1 = rot & 1, r2 = rot & 2;
+    // STORES IN WHOLE 128-BYTE LINES.  A chunk is a whole number of blocks, not of cache lines (17,712 bytes at
+    // [.,41,41,27]: chunk c starts 48 c mod 128 bytes into a line), and a wave's store instruction that starts inside a
+    // line leaves two partial lines behind.  That alone costs a plain copy of this tensor 12 % (scripts/d2s_ubench.hip:
+    // 15.6 us with the destination on a line boundary, 17.5 us 48 bytes off it; the source's alignment is free).  So the
+    // lane <-> float4 assignment of the OUTPUT side is shifted down by `shift` float4s: lane i gathers and stores the
+    // chunk's float4 i - shift, which makes every store instruction start on a line boundary (only the chunk's first
+    // and last line are shared with the neighbouring chunks).  All chunks of a workgroup start at the same offset
+    // into a line (the launcher makes the grid a multiple of the period, at most 8), so the shift -- and with it the
+    // gather table -- is fixed per workgroup.  Lanes left of the chunk get a negative buffer offset: out of range as
+    // an unsigned number, the store is dropped.
+    const int shift = (int)((reinterpret_cast<uintptr_t>(out) + (size_t)c * chunk_bytes) & 127u) >> 4;
+    // gather sources as LDS byte offsets inside a buffer, two per register (a buffer is < 64 KB): the DEPTH chunks of
+    // data in flight need the registers
+    unsigned spk[KMAX][2];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        const int i = k * 256 + threadIdx.x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sidx[k][e] = (i < c4) ? src_of(4 * i + ((e + rot) & 3)) : 0;
+        int t[4];
+        src_of.rotated(k * 256 + threadIdx.x - shift, c4, rot, t);
+        spk[k][0] = (unsigned)(t[0] * 4) | ((unsigned)(t[1] * 4) << 16);
+        spk[k][1] = (unsigned)(t[2] * 4) | ((unsigned)(t[3] * 4) << 16);
     }
-    const bool r1 = rot & 1, r2 = rot & 2;
-    int p = 0;
-    for (;;) {
-        const int n4 = n >> 2;
-        float* buf = lds + (DB ? p * chunk_floats : 0);
-        if (!DB) lds_barrier();   // single buffer: the previous chunk's gathers are done
+    const int store_off = lane_off - 16 * shift;
+    // LDS float4 slot of the last load slot: inside the chunk, or this thread's dummy slot
+    const int last_i = (KMAX - 1) * 256 + threadIdx.x;
+    const bool last_in = last_i < c4;
+    auto step = [&](u32x4v (&reg)[KMAX], int p, int cur) {
+        float* buf = lds + p * chunk_floats;
+        u32x4v* buf4 = reinterpret_cast<u32x4v*>(buf);
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int i = k * 256 + threadIdx.x;
-            if (i < n4) reinterpret_cast<f32x4*>(buf)[i] = v[k];
-        }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) buf[i] = in[c0 + i];
-        const size_t next = c0 + stride;
-        const bool more = next < total;
-        const int nn = more ? chunk_len(next) : 0;
-        if (more) issue_loads(next, nn >> 2);
+        for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = reg[k];
+        reinterpret_cast<u32x4v*>(lds)[last_in ? p * c4 + last_i : 2 * c4 + threadIdx.x] = reg[KMAX - 1];
+        issue(reg, cur + DEPTH * G);
         lds_barrier();
-        f32x4* gout = reinterpret_cast<f32x4*>(out + c0);
+        const __amdgpu_buffer_rsrc_t ro = rsrc_at(out, cur);
+        const char* bytes = reinterpret_cast<const char*>(buf);
+        constexpr int GB = 3;   // float4s gathered per batch: their LDS reads are issued together (one latency per batch)
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int i = k * 256 + threadIdx.x;
-            if (i < n4) {
-                float a0 = buf[sidx[k][0]], a1 = buf[sidx[k][1]], a2 = buf[sidx[k][2]], a3 = buf[sidx[k][3]];
-                // a_e = element (e + rot) % 4  ->  element j = a_{(j - rot) % 4}: rotate right by rot
-                float b0 = r1 ? a3 : a0, b1 = r1 ? a0 : a1, b2 = r1 ? a1 : a2, b3 = r1 ? a2 : a3;
-                f32x4 o;
-                o[0] = r2 ? b2 : b0; o[1] = r2 ? b3 : b1; o[2] = r2 ? b0 : b2; o[3] = r2 ? b1 : b3;
-                __builtin_nontemporal_store(o, gout + i);
+        for (int k0 = 0; k0 < KMAX; k0 += GB) {
+            float g[GB][4];
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < KMAX; ++k) {
+                g[k - k0][0] = *reinterpret_cast<const float*>(bytes + (spk[k][0] & 0xffffu));
+                g[k - k0][1] = *reinterpret_cast<const float*>(bytes + (spk[k][0] >> 16));
+                g[k - k0][2] = *reinterpret_cast<const float*>(bytes + (spk[k][1] & 0xffffu));
+                g[k - k0][3] = *reinterpret_cast<const float*>(bytes + (spk[k][1] >> 16));
+            }
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < KMAX; ++k) {
+                const f32x4 o = unrotate4(g[k - k0][0], g[k - k0][1], g[k - k0][2], g[k - k0][3], r1, r2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, store_off + k * 4096, 0, 2);
             }
         }
-        for (int o = (n4 << 2) + threadIdx.x; o < n; o += 256) out[c0 + o] = buf[src_of(o)];
-        if (!more) break;
-        c0 = next;
-        n = nn;
-        p ^= 1;
+    };
+    for (int n = 0; c < nfull; c += DEPTH * G, n += DEPTH) {   // n: chunks this workgroup has done (LDS buffer = parity)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) step(v[d], (n + d) & 1, c + d * G);
+    }
+}
+
+// One chunk per workgroup (grid = number of full chunks), one LDS buffer: the hardware's workgroup dispatcher does the
+// load balancing and seven workgroups share a CU, each with its chunk's loads in flight while it computes its gather
+// indices.  The index computation is paid per chunk instead of per persistent workgroup -- on the otherwise idle
+// vector ALU, under the chunk's own memory latency.
+template <int KMAX>
+__global__ __launch_bounds__(256) void subpixel_once_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int chunk_floats, SubpixelGeom geo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [chunk_floats] + [256][4] dummy slots
+    const int c = blockIdx.x;
+    const int c4 = chunk_floats >> 2;
+    const unsigned chunk_bytes = (unsigned)chunk_floats * 4u;
+    const int lane_off = threadIdx.x * 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)c * chunk_floats), 0,
+                                                                        chunk_bytes, 0x00020000);
+    u32x4v v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2 /* nt */);
+    const SubpixelIndex src_of(geo);
+    const int rot = (threadIdx.x >> 3) & 3;
+    const bool r1 = rot & 1, r2 = rot & 2;
+    // stores in whole 128-byte lines: the output side's lane <-> float4 assignment is shifted (see subpixel_pipe_kernel)
+    const int shift = (int)((reinterpret_cast<uintptr_t>(out) + (size_t)c * chunk_bytes) & 127u) >> 4;
+    int sidx[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) src_of.rotated(k * 256 + threadIdx.x - shift, c4, rot, sidx[k]);
+    const int last_i = (KMAX - 1) * 256 + threadIdx.x;
+    u32x4v* buf4 = reinterpret_cast<u32x4v*>(lds);
+#pragma unroll
+    for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = v[k];
+    buf4[last_i < c4 ? last_i : c4 + threadIdx.x] = v[KMAX - 1];
+    lds_barrier();
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)c * chunk_floats, 0, chunk_bytes, 0x00020000);
+    const int store_off = lane_off - 16 * shift;
+    float g[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[k][e] = lds[sidx[k][e]];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const f32x4 o = unrotate4(g[k][0], g[k][1], g[k][2], g[k][3], r1, r2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, store_off + k * 4096, 0, 2);
     }
 }
 
@@ -184,6 +403,20 @@ __global__ __launch_bounds__(256) void subpixel_direct_kernel(const float* __res
     }
 }
 
+// DEPTH * KMAX float4s of data per thread must fit beside the gather offsets in 128 registers (four workgroups per
+// CU): the instances that would spill are not built (K = 6, 7 at depth 2; K >= 6 at depth 3).
+template <int K>
+static void launch_subpixel_pipe(int depth, int grid, size_t lds, hipStream_t s, const float* in, float* out, int nfull, int chunk,
+                                 const SubpixelGeom& geo) {
+    if constexpr (K <= 5) {
+        if (depth >= 3) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 3>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
+    }
+    if constexpr (K <= 5 || K == 8) {
+        if (depth >= 2) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 2>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
+    }
+    hipLaunchKernelGGL((subpixel_pipe_kernel<K, 1>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo);
+}
+
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
                            const SubpixelTune& kn, hipStream_t s) {
     const int rC = r * C;
@@ -195,28 +428,58 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
     size_t RB = 4;
     if (B % 4 == 0) RB = 1; else if (B % 2 == 0) RB = 2;
     if (RB * B * 4 <= lds_cap && B < (1u << 20)) {
+        const SubpixelGeom geo = subpixel_geom(W, rC, r, inverse);
         const size_t target = (size_t)kn.chunk_kb * 1024;
         while (2 * RB * B * 4 <= target) RB *= 2;   // ~16-24 KiB chunks: several workgroups per CU
         const int chunk = (int)(RB * B);
-        size_t nchunks = (total + chunk - 1) / chunk;
-        // two LDS buffers (loads of the next chunk in flight during the gather) while four workgroups still share a CU
-        const bool db = kn.db && (size_t)chunk * 8 <= 40 * 1024;
-        // persistent workgroups: the index precomputation is paid once per workgroup
-        const size_t cap = (size_t)(kn.grid > 0 ? kn.grid : 1024);
-        int grid = (int)(nchunks < cap ? nchunks : cap);
-        const int kneed = (chunk / 4 + 255) / 256;
-        const size_t lds = (size_t)chunk * 4 * (db ? 2 : 1);
-#define SRX_SUBPIXEL_LAUNCH2(INV, K, DBUF)                                                                      \
-        hipLaunchKernelGGL((subpixel_lds_kernel<INV, K, DBUF>), dim3(grid), dim3(256), lds, s, in, out, total,  \
-                           (int)B, chunk, W, rC, r);
+        const size_t nchunks = (total + chunk - 1) / chunk;
+        const size_t cap = (size_t)(kn.grid > 0 ? kn.grid : 1024);   // persistent workgroups: the index precomputation is paid once each
+        const int kneed = (chunk / 4 + 7 + 255) / 256;   // (+7: the pipelined kernel's output side is shifted by up to 7 float4s)
+        // the software-pipelined kernel: two LDS buffers + the dummy slots while four workgroups still share a CU
+        const size_t pipe_lds = (size_t)chunk * 8 + 4096;
+        size_t nfull = kn.db && pipe_lds <= 40 * 1024 && kneed <= 8 && nchunks < (1u << 28) ? total / chunk : 0;
+        if (nfull && kn.db == 2) {
+            const size_t once_lds = (size_t)chunk * 4 + 4096;
+#define SRX_SUBPIXEL_ONCE(K)                                                                                     \
+            case K:                                                                                              \
+                hipLaunchKernelGGL((subpixel_once_kernel<K>), dim3((unsigned)nfull), dim3(256), once_lds, s, in, out, chunk, geo); \
+                break;
+            switch (kneed) {
+                SRX_SUBPIXEL_ONCE(1) SRX_SUBPIXEL_ONCE(2) SRX_SUBPIXEL_ONCE(3) SRX_SUBPIXEL_ONCE(4)
+                SRX_SUBPIXEL_ONCE(5) SRX_SUBPIXEL_ONCE(6) SRX_SUBPIXEL_ONCE(7) SRX_SUBPIXEL_ONCE(8)
+            }
+#undef SRX_SUBPIXEL_ONCE
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        } else if (nfull) {
+            int grid = (int)(nfull < cap ? nfull : cap);
+            if ((size_t)grid < nfull) grid -= grid % 8;   // every chunk of a workgroup starts at the same offset into a 128-byte line
+#define SRX_SUBPIXEL_PIPE(K) case K: launch_subpixel_pipe<K>(depth, grid, pipe_lds, s, in, out, (int)nfull, chunk, geo); break;
+            // chunks of loads in flight per workgroup
+            const int per_wg = (int)((nfull + grid - 1) / grid);
+            const int depth = kn.depth > 0 ? (kn.depth < per_wg ? kn.depth : per_wg) : 1;   // (measured: deeper is slower)
+            switch (kneed) {
+                SRX_SUBPIXEL_PIPE(1) SRX_SUBPIXEL_PIPE(2) SRX_SUBPIXEL_PIPE(3) SRX_SUBPIXEL_PIPE(4)
+                SRX_SUBPIXEL_PIPE(5) SRX_SUBPIXEL_PIPE(6) SRX_SUBPIXEL_PIPE(7) SRX_SUBPIXEL_PIPE(8)
+            }
+#undef SRX_SUBPIXEL_PIPE
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        const size_t done = nfull * (size_t)chunk;
+        if (done < total) {   // everything (single-buffer route) or the ragged last chunk
+            const float* tin = in + done;
+            float* tout = out + done;
+            const size_t ttotal = total - done;
+            const size_t tchunks = (ttotal + chunk - 1) / chunk;
+            const int grid = (int)(tchunks < cap ? tchunks : cap);
 #define SRX_SUBPIXEL_LAUNCH(K)                                                                                   \
-        if (inverse) { if (db) { SRX_SUBPIXEL_LAUNCH2(true, K, true) } else { SRX_SUBPIXEL_LAUNCH2(true, K, false) } }    \
-        else { if (db) { SRX_SUBPIXEL_LAUNCH2(false, K, true) } else { SRX_SUBPIXEL_LAUNCH2(false, K, false) } }
-        if (kneed <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
-        else if (kneed <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
-        else { SRX_SUBPIXEL_LAUNCH(12) }
+            hipLaunchKernelGGL((subpixel_lds_kernel<K>), dim3(grid), dim3(256), chunk * 4, s, tin, tout, ttotal, chunk, geo);
+            if (kneed <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
+            else if (kneed <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
+            else { SRX_SUBPIXEL_LAUNCH(12) }
 #undef SRX_SUBPIXEL_LAUNCH
-#undef SRX_SUBPIXEL_LAUNCH2
+        }
     } else {
         if (B >= (1u << 22)) return hipErrorInvalidValue;
         size_t nb = (total + 255) / 256;

@@ -1,0 +1,230 @@
+// d2s_ubench.hip -- diagnostic: where do the ~1.8 us between a plain streaming copy (15.6 us) and the sub-pixel map
+// (17.4 us) at [256,41,41,27] (46.5 MB in, 46.5 MB out) go?  The map's structure is rebuilt step by step around a copy:
+//   A  grid-stride copy, 8 float4 per thread in flight, 2048 workgroups                      (= srx_stream_copy)
+//   B  the map's chunking: 1024 persistent workgroups, chunks of 4428 floats (5 float4 slots per thread, the last one
+//      ragged), next chunk's loads issued before the current chunk's stores, bounds-checked buffer operations, NO LDS
+//   C  B + every chunk written to LDS (b128) and read back with 4 x ds_read_b32 per float4 at the IDENTITY index
+//      (the map's LDS traffic and barrier without its index arithmetic and bank pattern)
+//   D  C with the map's real gather indices read from a table in global memory (no index arithmetic in the kernel)
+//   E  one chunk per workgroup (2624 workgroups), no LDS
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/d2s_ubench.hip -o scripts/d2s_ubench.bin ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KMAX, bool NT = true>
+__global__ __launch_bounds__(256) void copy_a(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t n4) {
+    const size_t per = (size_t)KMAX * 256;
+    for (size_t base = (size_t)blockIdx.x * per; base < n4; base += (size_t)gridDim.x * per) {
+        f32x4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < n4) v[k] = NT ? __builtin_nontemporal_load(in + i) : in[i]; }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < n4) { if (NT) __builtin_nontemporal_store(v[k], out + i); else out[i] = v[k]; } }
+    }
+}
+
+// MODE 0: no LDS (B / E)   1: LDS, identity gather (C)   2: LDS, gather through a table (D)
+template <int KMAX, int MODE, int AUX = 2, bool CONTIG = false>
+__global__ __launch_bounds__(256) void chunked(const float* __restrict__ in, float* __restrict__ out, int nfull, int chunk_floats,
+                                               const int* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // CONTIG: a workgroup owns a contiguous range of chunks instead of every G-th one
+    const int per = (nfull + gridDim.x - 1) / gridDim.x;
+    int c = CONTIG ? blockIdx.x * per : blockIdx.x;
+    const int cend = CONTIG ? (c + per < nfull ? c + per : nfull) : nfull;
+    if (c >= nfull) return;
+    const int G = CONTIG ? 1 : gridDim.x;
+    const int c4 = chunk_floats >> 2;
+    const unsigned chunk_bytes = (unsigned)chunk_floats * 4u;
+    const int lane_off = threadIdx.x * 16;
+    auto rsrc_at = [&](const float* base, int chunk) {
+        const bool ok = chunk < cend;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)(ok ? chunk : 0) * chunk_floats), 0, ok ? chunk_bytes : 0u, 0x00020000);
+    };
+    u32x4v v[KMAX];
+    auto issue = [&](int chunk) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_at(in, chunk);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, AUX);
+    };
+    issue(c);
+    {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_at(out, cend);
+        const u32x4v z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rs, lane_off + k * 4096, 0, AUX);
+    }
+    int sidx[KMAX][4];
+    if (MODE) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sidx[k][e] = i < c4 ? (MODE == 2 ? table[4 * i + e] : 4 * i + e) : 0;
+        }
+    }
+    const int last_i = (KMAX - 1) * 256 + threadIdx.x;
+    const bool last_in = last_i < c4;
+    int p = 0;
+    for (; c < cend; c += G, p ^= 1) {
+        const __amdgpu_buffer_rsrc_t ro = rsrc_at(out, c);
+        if (MODE == 0) {
+            u32x4v w[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) w[k] = v[k];
+            issue(c + G);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) __builtin_amdgcn_raw_buffer_store_b128(w[k], ro, lane_off + k * 4096, 0, AUX);
+        } else {
+            float* buf = lds + p * chunk_floats;
+            u32x4v* buf4 = reinterpret_cast<u32x4v*>(buf);
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = v[k];
+            reinterpret_cast<u32x4v*>(lds)[last_in ? p * c4 + last_i : 2 * c4 + threadIdx.x] = v[KMAX - 1];
+            issue(c + G);
+            lds_barrier();
+            float g[KMAX][4];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[k][e] = buf[sidx[k][e]];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                f32x4 o; o[0] = g[k][0]; o[1] = g[k][1]; o[2] = g[k][2]; o[3] = g[k][3];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, lane_off + k * 4096, 0, AUX);
+            }
+        }
+    }
+}
+
+// every chunk of the workgroup (at most DEPTH) requested before the first one is touched; MODE as in `chunked`
+template <int KMAX, int DEPTH, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void upfront(const float* __restrict__ in, float* __restrict__ out, int nfull, int chunk_floats, const int* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c = blockIdx.x, G = gridDim.x;
+    if (c >= nfull) return;
+    const int c4 = chunk_floats >> 2;
+    const unsigned chunk_bytes = (unsigned)chunk_floats * 4u;
+    const int lane_off = threadIdx.x * 16;
+    auto rsrc_at = [&](const float* base, int chunk) {
+        const bool ok = chunk < nfull;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)(ok ? chunk : 0) * chunk_floats), 0, ok ? chunk_bytes : 0u, 0x00020000);
+    };
+    u32x4v v[DEPTH][KMAX];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_at(in, c + d * G);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[d][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2);
+    }
+    unsigned short sidx[KMAX][4];
+    if (MODE) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = k * 256 + threadIdx.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sidx[k][e] = (unsigned short)(i < c4 ? (MODE == 2 ? table[4 * i + e] : 4 * i + e) : 0);
+        }
+    }
+    const int last_i = (KMAX - 1) * 256 + threadIdx.x;
+    const bool last_in = last_i < c4;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const __amdgpu_buffer_rsrc_t ro = rsrc_at(out, c + d * G);
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) __builtin_amdgcn_raw_buffer_store_b128(v[d][k], ro, lane_off + k * 4096, 0, 2);
+        } else {
+            const int p = d & 1;
+            float* buf = lds + p * chunk_floats;
+            u32x4v* buf4 = reinterpret_cast<u32x4v*>(buf);
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = v[d][k];
+            reinterpret_cast<u32x4v*>(lds)[last_in ? p * c4 + last_i : 2 * c4 + threadIdx.x] = v[d][KMAX - 1];
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = buf[sidx[k][e]];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, lane_off + k * 4096, 0, 2);
+            }
+        }
+    }
+}
+
+int main() {
+    const int P = 8;
+    const size_t nfl = (size_t)256 * 41 * 41 * 27;
+    const int chunk = 4 * 41 * 3 * 9;   // 4428 floats
+    const int nfull = (int)(nfl / chunk);
+    std::vector<float*> in(P), out(P);
+    for (int i = 0; i < P; ++i) { CK(hipMalloc(&in[i], nfl * 4)); CK(hipMalloc(&out[i], nfl * 4)); CK(hipMemset(in[i], 1, nfl * 4)); CK(hipMemset(out[i], 0, nfl * 4)); }
+    // the map's gather table of one chunk (depth-to-space, W = 41, rC = 9, r = 3)
+    std::vector<int> tab(chunk);
+    { const int W = 41, rC = 9, r = 3, B = W * r * rC;
+      for (int o = 0; o < chunk; ++o) { int blk = o / B, oo = o % B, dy = oo / (W * rC), rest = oo % (W * rC), w = rest / rC, j = rest % rC; tab[o] = blk * B + w * r * rC + dy * rC + j; } }
+    int* dtab; CK(hipMalloc(&dtab, chunk * 4)); CK(hipMemcpy(dtab, tab.data(), chunk * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const size_t lds2 = (size_t)chunk * 8 + 4096;
+    auto timeit = [&](const char* name, auto launch) {
+        for (int i = 0; i < 2 * P; ++i) launch(i % P);
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 80; ++i) launch(i % P);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms / 80 < best) best = ms / 80;
+        }
+        CK(hipGetLastError());
+        printf("%-70s %6.2f us  %5.2f TB/s\n", name, best * 1e3, 2.0 * nfl * 4 / (best * 1e-3) / 1e12);
+    };
+    timeit("A  grid-stride copy, 8 float4/thread, 2048 wgs", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(2048), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("A' grid-stride copy, 4 float4/thread, 2048 wgs", [&](int i) { hipLaunchKernelGGL(copy_a<4>, dim3(2048), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("A'' grid-stride copy, 8 float4/thread, 1024 wgs", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1024), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("B  chunked 4428 floats, 1024 persistent wgs, prefetch 1, no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("B' the same with the map's LDS allocation (4 wgs per CU)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("C  B' + through LDS, identity gather", [&](int i) { hipLaunchKernelGGL((chunked<5, 1>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("D  B' + through LDS, the map's gather indices from a table", [&](int i) { hipLaunchKernelGGL((chunked<5, 2>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("E  one chunk per workgroup (2624 wgs), no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(nfull), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("E' one chunk per workgroup, 22 KB of LDS each (7 per CU)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(nfull), dim3(256), 22 * 1024, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("A1 copy, 8 float4/thread, 1419 wgs (exactly one round, no idle wg)", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("A2 copy, 8 float4/thread, 2048 wgs, plain (not nontemporal) loads and stores", [&](int i) { hipLaunchKernelGGL((copy_a<8, false>), dim3(2048), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("A3 copy, 6 float4/thread, 1892 wgs (one round)", [&](int i) { hipLaunchKernelGGL(copy_a<6>, dim3(1892), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("A4 copy, 12 float4/thread, 946 wgs (one round)", [&](int i) { hipLaunchKernelGGL(copy_a<12>, dim3(946), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], nfl / 4); });
+    timeit("B2 B with plain (not nontemporal) accesses", [&](int i) { hipLaunchKernelGGL((chunked<5, 0, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("B3 B, each workgroup a contiguous range of chunks", [&](int i) { hipLaunchKernelGGL((chunked<5, 0, 2, true>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("B4 B with 875 wgs (3 chunks each)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(875), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("B5 B with 1312 wgs (2 chunks each, 5.1 per CU)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1312), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("D3 D, contiguous ranges", [&](int i) { hipLaunchKernelGGL((chunked<5, 2, 2, true>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("U0 all 3 chunks of a workgroup requested up front, 1024 wgs, no LDS", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("U0' the same, 875 wgs (3 chunks each)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0>), dim3(875), dim3(256), 0, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("U1 up front + through LDS, identity gather", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 1>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("U2 up front + through LDS, the map's gather from a table", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 2>), dim3(1024), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("U2' the same, 875 wgs", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 2>), dim3(875), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    timeit("M1 copy A1 (1419 wgs), source 48 bytes off a 128-byte line", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)(in[i] + 12), (f32x4*)out[i], nfl / 4 - 8); });
+    timeit("M2 copy A1, destination 48 bytes off", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)(out[i] + 12), nfl / 4 - 8); });
+    timeit("M3 copy A1, both 48 bytes off", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)(in[i] + 12), (f32x4*)(out[i] + 12), nfl / 4 - 8); });
+    timeit("M4 copy A1, both 64 bytes off", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)(in[i] + 16), (f32x4*)(out[i] + 16), nfl / 4 - 8); });
+    {   // line-aligned chunks: 4608 floats = 144 lines of 128 bytes (the map's chunks are 138.375 lines)
+        const int ca = 4608, na = (int)(nfl / ca);
+        const size_t la = (size_t)ca * 8 + 4096;
+        timeit("Ba B with line-aligned chunks (4608 floats)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
+        timeit("Ca C with line-aligned chunks", [&](int i) { hipLaunchKernelGGL((chunked<5, 1>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca, dtab); });
+        timeit("Ea E with line-aligned chunks (one chunk per workgroup)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(na), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
+        timeit("Ua U0 with line-aligned chunks (all up front, no LDS)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
+        timeit("Ua1 U1 with line-aligned chunks (all up front, LDS identity)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 1>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca, dtab); });
+    }
+    timeit("F  D with 2624 wgs (one chunk each)", [&](int i) { hipLaunchKernelGGL((chunked<5, 2>), dim3(nfull), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
+    return 0;
+}

@@ -1,23 +1,50 @@
 #!/usr/bin/env python3
 """HIP-event timing of the sub-pixel map at the north-star bandwidth shape
-[256,41,41,27] <-> [256,123,123,3] with 4 rotating buffer pairs (372 MB > 256 MiB Infinity Cache)."""
-import os, sys
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ml_super_resolution_amd import ops
-dev = torch.device('cuda')
-bufs = [torch.rand((256, 41, 41, 27), device=dev) for _ in range(4)]
-outs = [torch.empty((256, 123, 123, 3), device=dev) for _ in range(4)]
-def run(fn, iters=40):
-    for i in range(8): fn(i)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for i in range(iters): fn(i)
-    e.record(); e.synchronize()
-    return s.elapsed_time(e) / iters * 1e3
-t1 = run(lambda i: ops.depth_to_space(bufs[i % 4], 3, out=outs[i % 4]))
-t2 = run(lambda i: ops.space_to_depth(outs[i % 4], 3, out=bufs[i % 4]))
-t3 = run(lambda i: outs[i % 4].view(-1).copy_(bufs[i % 4].view(-1)))
-by = 2 * 256 * 41 * 41 * 27 * 4
-print('d2s %.1f us  %.2f TB/s (%.1f%% of 8 TB/s) | s2d %.1f us %.2f TB/s | torch copy_ same bytes %.1f us %.2f TB/s'
-      % (t1, by / t1 / 1e6, 100 * by / t1 / 1e6 / 8, t2, by / t2 / 1e6, t3, by / t3 / 1e6))
+[256,41,41,27] <-> [256,123,123,3] with 8 rotating buffer pairs (744 MB > 256 MiB Infinity Cache), beside two plain
+copies of the same bytes: the library's own streaming copy (srx_stream_copy: nontemporal 16-byte loads / stores,
+persistent workgroups -- the ceiling of a byte-moving kernel at this transfer size) and torch's copy_.
+
+  python scripts/time_d2s.py            one line for the current environment
+  python scripts/time_d2s.py sweep      the tuning knobs, one fresh process each (they are read once per process)
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SWEEP = [{}, {'SRX_SUBPIXEL_DB': '2'}, {'SRX_SUBPIXEL_DB': '0'}, {'SRX_SUBPIXEL_GRID': '768'}, {'SRX_SUBPIXEL_GRID': '1280'}]
+
+
+def one():
+    import torch
+    from ml_super_resolution_amd import ops
+    dev = torch.device('cuda')
+    P = 8
+    bufs = [torch.rand((256, 41, 41, 27), device=dev) for _ in range(P)]
+    outs = [torch.empty((256, 123, 123, 3), device=dev) for _ in range(P)]
+
+    def run(fn, iters=80):
+        for i in range(2 * P): fn(i)
+        best = 1e9
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for i in range(iters): fn(i)
+            e.record(); e.synchronize()
+            best = min(best, s.elapsed_time(e) / iters * 1e3)
+        return best
+    t1 = run(lambda i: ops.depth_to_space(bufs[i % P], 3, out=outs[i % P]))
+    t2 = run(lambda i: ops.space_to_depth(outs[i % P], 3, out=bufs[i % P]))
+    t4 = run(lambda i: ops.stream_copy(bufs[i % P], outs[i % P]))
+    t3 = run(lambda i: outs[i % P].view(-1).copy_(bufs[i % P].view(-1)))
+    by = 2 * 256 * 41 * 41 * 27 * 4
+    knobs = ' '.join('%s=%s' % (k, v) for k, v in os.environ.items() if k.startswith('SRX_SUBPIXEL'))
+    print('%-40s d2s %.2f us %.2f TB/s (%.1f%% of 8 TB/s) | s2d %.2f us %.2f TB/s | srx_stream_copy %.2f us %.2f TB/s | torch copy_ %.2f us %.2f TB/s'
+          % (knobs or 'defaults', t1, by / t1 / 1e6, 100 * by / t1 / 1e6 / 8, t2, by / t2 / 1e6, t4, by / t4 / 1e6, t3, by / t3 / 1e6), flush=True)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+        for env in SWEEP:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, **env))
+    else:
+        one()

@@ -196,6 +196,27 @@ def test_subpixel_bit_exact(r, ops, golden_d2s):
         np.testing.assert_array_equal(back.view(torch.int32).cpu().numpy().view(np.uint32), bits)
 
 
+def test_subpixel_random_shapes_every_kernel_route(ops):
+    """Random (N, H, W, C, r) incl. C = 1..4, r = 1..4 (runs shorter than 4 floats take the odometer path of the index
+    arithmetic), rows of 1 pixel, ragged last chunks behind the pipelined kernel (N * H not a multiple of the blocks
+    per chunk), several chunks per workgroup, rows too long for two LDS buffers (single-buffer kernel) and for LDS at all
+    (direct kernel): depth-to-space against the oracle's index map, space-to-depth as its inverse, as integers."""
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 90)), int(rng.integers(1, 5)), int(rng.integers(1, 5)))
+              for _ in range(60)]
+    shapes += [(2, 3, 1100, 3, 3), (1, 2, 4000, 3, 2), (1, 1, 700, 4, 4), (700, 41, 41, 3, 3), (3, 1500, 9, 1, 2), (1, 5, 333, 3, 4)]
+    for (n, h, w, c, r) in shapes:
+        bits = rng.integers(0, 1 << 32, size=(n, h, w, c * r * r), dtype=np.uint64).astype(np.uint32)
+        t = torch.from_numpy(bits.view(np.int32)).cuda().view(torch.float32)
+        d = ops.depth_to_space(t, r)
+        if n * h * w <= 200000:
+            np.testing.assert_array_equal(d.view(torch.int32).cpu().numpy().view(np.uint32), O.depth_to_space(bits, r), err_msg=str((n, h, w, c, r)))
+        else:
+            np.testing.assert_array_equal(d[::53].view(torch.int32).cpu().numpy().view(np.uint32), O.depth_to_space(bits[::53], r))
+        back = ops.space_to_depth(d, r)
+        assert torch.equal(back.view(torch.int32), t.view(torch.int32)), (n, h, w, c, r)
+
+
 def test_subpixel_full_size_roundtrip(ops):
     """north-star bandwidth shape [256,41,41,27] <-> [256,123,123,3]: d2s o s2d = id, and a
     checksum of checksums against the oracle's index map on a strided sample."""
