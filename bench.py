@@ -128,16 +128,20 @@ def cpu_library_baseline(rank):
                 t_.grad = None
 
         step()
+        # best of at least three repetitions (the host is shared: between two runs of this leg the AVERAGE moved 137 <-> 523
+        # patches/s; the fastest repetition is the one the other tenants disturbed least), thread count pinned above
         t0 = time.perf_counter()
-        reps = 0
+        times = []
         while True:
+            t1 = time.perf_counter()
             step()
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt > 8.0 or reps >= 6:
+            times.append(time.perf_counter() - t1)
+            if len(times) >= 3 and (time.perf_counter() - t0 > 8.0 or len(times) >= 8):
                 break
-        return {'value': round(n * reps / dt, 2), 'unit': 'patches/s', 'cores': int(threads), 'kind': 'library stand-in',
-                'sample': '%d x VDSR-20 fwd+bwd on %d patches of 41x41 (torch %s CPU conv2d + autograd, fp32)' % (reps, n, torch.__version__)}
+        best = min(times)
+        return {'value': round(n / best, 2), 'unit': 'patches/s', 'cores': int(threads), 'kind': 'library stand-in',
+                'statistic': 'best of %d repetitions (mean %.2f patches/s)' % (len(times), n * len(times) / sum(times)),
+                'sample': '%d x VDSR-20 fwd+bwd on %d patches of 41x41 (torch %s CPU conv2d + autograd, fp32)' % (len(times), n, torch.__version__)}
     except Exception as exc:     # a comparator, not part of the measurement
         return {'value': None, 'error': repr(exc)}
 
