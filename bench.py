@@ -255,6 +255,11 @@ def extras(model, dev, stream, x64, y64, px):
     us = hip_event_time_ms(c1, 100, stream) * 1e3
     out['srcnn_c1_us'] = round(us, 2)
     out['srcnn_c1_tflops'] = round(2200e6 / (us * 1e-6) / 1e12, 2)
+    c3 = lambda: sm.forward(img, single_launch=False)
+    for _ in range(5):
+        c3()
+    out['srcnn_c1_three_launches_us'] = round(hip_event_time_ms(c3, 100, stream) * 1e3, 2)
+    out['srcnn_c1_path'] = 'one launch: 9-1-5 chained through LDS per 15x15 output tile (srx_srcnn_forward), bit-identical to the three launches'
     del sm, img, e3, lr
     # -- BASELINE configs[4] as the reference trains it (enet/enet/experiment_train.py:15-22): EnhanceNet-PAT, batch 64 of
     #    32x32 -> 128x128 patches, VGG-19 perceptual + texture + adversarial losses (random VGG-shaped weights: the real

@@ -177,6 +177,15 @@ int srx_espcn_forward(const float* x, const float* w1, const float* b1, const fl
                       const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
                       srx_stream_t stream);
 
+/* SRCNN inference in ONE launch (srcnn/srcnn.py:100-130, tf.contrib.layers.convolution2d x 3, padding 'VALID'):
+ *   t1 = relu(conv9x9(x; 3->64) + b1), t2 = relu(conv1x1(t1; 64->32) + b2), y = tanh(conv5x5(t2; 32->3) + b3)
+ * x [N,H,W,3] (H, W >= 13), filters HWIO ([9,9,3,64], [1,1,64,32], [5,5,32,3]), y [N,H-12,W-12,3].  A workgroup chains the
+ * three layers through LDS for a tile of <= 15x15 output pixels; bit-identical to three srx_conv2d_fwd launches.  For
+ * latency-bound problems (BASELINE configs[0]: one 243x243 image = 256 tiles, one per CU); halo pixels of the hidden
+ * layers are recomputed per tile (x1.6), so large batches stay on the per-layer launches.  b1 / b2 16-byte aligned. */
+int srx_srcnn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* w3, const float* b3, float* y, int N, int H, int W, srx_stream_t stream);
+
 /* Inverse map (HR image -> sub-pixel label layout): in [N,H*r,W*r,C] -> out [N,H,W,C*r*r].
  * Replaces espcn/espcn/dataset.py:140-156 and espcn/espcn/experiment_test.py:91-96. */
 int srx_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int r,

@@ -174,6 +174,24 @@ def espcn_forward(x, params, r, out=None):
     return out
 
 
+def srcnn_forward(x, params, out=None):
+    """SRCNN 9-1-5 VALID inference in one launch -- srx_srcnn_forward.  params = [(w1, b1), (w2, b2), (w3, b3)] (HWIO kernels);
+    x [N,H,W,3] -> [N,H-12,W-12,3]."""
+    _chk(x, 'x')
+    for k, b in params:
+        _chk(k, 'kernel'); _chk(b, 'bias')
+    (w1, b1), (w2, b2), (w3, b3) = params
+    N, H, W, C = x.shape
+    if C != 3 or tuple(w1.shape) != (9, 9, 3, 64) or tuple(w2.shape) != (1, 1, 64, 32) or tuple(w3.shape) != (5, 5, 32, 3):
+        raise ValueError('srcnn_forward: shapes do not describe SRCNN 9-1-5')
+    if H < 13 or W < 13:
+        raise ValueError('srcnn_forward: image %dx%d smaller than the 13-pixel receptive field' % (H, W))
+    out = out if out is not None else torch.empty((N, H - 12, W - 12, 3), dtype=torch.float32, device=x.device)
+    check(lib().srx_srcnn_forward(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out),
+                                  N, H, W, _stream()), 'srx_srcnn_forward')
+    return out
+
+
 def space_to_depth(x, r, out=None):
     """[N,H*r,W*r,C] -> [N,H,W,C*r*r]."""
     _chk(x, 'x')

@@ -82,6 +82,12 @@ class SrcnnModel(object):
         for i in range(3):
             truncated_normal_(self.stack.kernel(i), 0.001, gen)    # srcnn.py:84; biases zero
         self.placeholders = {}
+        self.use_single_launch = os.environ.get('SRX_SRCNN_FUSED', '1') != '0'
+        # one round of 15 x 15 tiles over the 256 CUs; below ~36 tiles the three launches' latency is the shorter chain
+        # (measured, scripts/time_srcnn.py: 1 x 243^2 66 vs 90 us, 64 x 33^2 50 vs 79 us; 1 x 256^2 -- 289 tiles, two rounds --
+        # 119 vs 93 us; 1 x 33^2 49 vs 40 us)
+        self.single_launch_max_pixels = int(os.environ.get('SRX_SRCNN_FUSED_MAX_PIXELS', '57600'))
+        self.single_launch_min_pixels = int(os.environ.get('SRX_SRCNN_FUSED_MIN_PIXELS', '8000'))
 
     def crop_side(self):
         f = self.flags
@@ -95,8 +101,21 @@ class SrcnnModel(object):
         lo = ops.resize_bicubic_tf(hd_images.contiguous(), h // f, w // f)
         return ops.resize_bicubic_tf(lo, h, w)
 
-    def forward(self, sd_images, keep=False):
-        """[N,S,S,3] bicubic-interpolated input -> [N,S-12,S-12,3] (VALID 9-1-5)."""
+    def forward(self, sd_images, keep=False, single_launch=None):
+        """[N,S,S,3] bicubic-interpolated input -> [N,S-12,S-12,3] (VALID 9-1-5).
+        Inference (keep=False) of latency-bound sizes -- `single_launch_min_pixels` .. `single_launch_max_pixels` output pixels: BASELINE configs[0]'s
+        one image is 231 x 231 = 256 tiles, one per CU -- runs as ONE launch that chains the three layers through LDS
+        (srx_srcnn_forward, bit-identical to the three launches); larger problems and training keep the per-layer
+        launches, whose activations backward needs."""
+        f = self.flags
+        if single_launch is None:
+            n, h, w, _ = sd_images.shape
+            single_launch = (self.use_single_launch and not keep and sd_images.is_cuda and (f.srcnn_f1, f.srcnn_f2, f.srcnn_f3) == (9, 1, 5)
+                             and (f.srcnn_n1, f.srcnn_n2) == (64, 32) and h >= 13 and w >= 13
+                             and self.single_launch_min_pixels <= n * (h - 12) * (w - 12) <= self.single_launch_max_pixels)
+        if single_launch:
+            params = [(self.stack.kernel(i), self.stack.bias(i)) for i in range(3)]
+            return ops.srcnn_forward(sd_images.contiguous(), params)
         return self.stack.forward(sd_images, keep=keep)
 
     def train_step(self, sd_images, hd_images_cropped):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[0]: SRCNN 9-1-5 (VALID) forward on one image, as the reference would run it (256 -> 243 crop,
-RGB): 2.2 GFLOP, three launches."""
+RGB): 2.2 GFLOP; three launches against ONE (srx_srcnn_forward: the layers chained through LDS per 15x15 output tile)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,14 +16,20 @@ def fwd(x):
     t = ops.conv2d_fwd(x, w1, b1, 'valid', 'relu')
     t = ops.conv2d_fwd(t, w2, b2, 'valid', 'relu')
     return ops.conv2d_fwd(t, w3, b3, 'valid', 'tanh')
-for n, hw in ((1, 243), (1, 256), (16, 243)):
-    x = rnd(n, hw, hw, 3)
-    for _ in range(10): fwd(x)
+params = [(w1, b1), (w2, b2), (w3, b3)]
+def timed(fn):
+    for _ in range(10): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(100): y = fwd(x)
+    for _ in range(100): fn()
     e.record(); e.synchronize()
-    us = s.elapsed_time(e) / 100 * 1e3
+    return s.elapsed_time(e) / 100 * 1e3
+for n, hw in ((1, 243), (1, 256), (2, 243), (4, 243), (16, 243), (1, 33), (64, 33)):
+    x = rnd(n, hw, hw, 3)
+    us = timed(lambda: fwd(x))
+    us1 = timed(lambda: ops.srcnn_forward(x, params))
+    same = torch.equal(fwd(x), ops.srcnn_forward(x, params))
     oh = hw - 12
     flop = 2.0 * n * (oh + 4) ** 2 * (243 * 64 + 64 * 32) + 2.0 * n * oh * oh * 800 * 3
-    print('SRCNN 9-1-5 forward %2d x %dx%d -> %dx%d: %7.1f us  %6.2f TFLOP/s  %7.2f MP/s out' % (n, hw, hw, oh, oh, us, flop / us / 1e6, n * oh * oh / us))
+    print('SRCNN 9-1-5 forward %2d x %dx%d -> %dx%d: three launches %7.1f us (%6.2f TFLOP/s) | one launch %7.1f us (%6.2f TFLOP/s, %7.2f MP/s out) bit-identical: %s'
+          % (n, hw, hw, oh, oh, us, flop / us / 1e6, us1, flop / us1 / 1e6, n * oh * oh / us1, same))

@@ -116,3 +116,32 @@ def test_espcn_graphs_of_several_shapes_own_their_buffers():
     for x, w in zip(reversed(xs), reversed(want)):
         assert torch.equal(m.super_resolve(x, use_graph=True, single_launch=False), w)
     del junk
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 243, 243), (2, 33, 33), (1, 13, 13), (3, 20, 47), (1, 28, 27), (1, 14, 40), (5, 43, 44)],
+                         ids=['config1', 'train_patch', 'one_pixel_out', 'ragged_tiles', 'tile_plus_one', 'short_wide', 'two_rounds'])
+def test_srcnn_single_launch_equals_three_launches(n, h, w):
+    """srx_srcnn_forward (9-1-5 VALID chained through LDS per <= 15x15 output tile, one launch; srcnn/srcnn.py:100-130)
+    against the three per-layer launches: the same products in the same order -> bit-identical; and <= 1e-3 (elementwise
+    bound) against the oracle.  Shapes: BASELINE configs[0] as the reference crops it (243 -> 231: 16 x 16 tiles, one per
+    CU); the reference's 33 x 33 training patch; the smallest image; tiles that do not divide the output; more tiles than
+    CUs."""
+    from ml_super_resolution_amd import ops
+    from ml_super_resolution_amd.srcnn import srcnn as srcnn_mod
+    m = srcnn_mod.SrcnnModel(device='cuda', seed=300 + h)
+    for i, s in enumerate((40.0, 80.0, 30.0)):             # O(1) activations instead of the reference's sigma 1e-3
+        m.stack.kernel(i).mul_(s)
+        m.stack.bias(i).uniform_(-0.1, 0.1)
+    g = torch.Generator(device='cuda').manual_seed(n * 1000 + h * 10 + w)
+    x = torch.rand((n, h, w, 3), device='cuda', generator=g) * 2 - 1
+    one = m.forward(x, single_launch=True).clone()
+    three = m.forward(x, single_launch=False).clone()
+    assert one.shape == (n, h - 12, w - 12, 3)
+    assert torch.equal(one, three), float((one - three).abs().max())
+    params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
+    close(one, O.srcnn_forward(x.cpu().numpy(), params))
+    assert float(one.abs().max()) > 0.05                   # (not a test of zeros)
+    # the default route (one launch for latency-bound sizes, three otherwise): the same bits either way
+    assert torch.equal(m.forward(x), one)
+    with pytest.raises(ValueError):
+        ops.srcnn_forward(x[:, :12], [(m.stack.kernel(i), m.stack.bias(i)) for i in range(3)])
