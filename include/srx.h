@@ -357,6 +357,11 @@ int srx_u8_to_pm1(const uint8_t* in, float* out, size_t n, srx_stream_t stream);
 int srx_maxpool2x2(const float* in, float* out, int N, int H, int W, int C, srx_stream_t stream);
 int srx_maxpool2x2_bwd(const float* x, const float* dout, float* din, int N, int H, int W, int C,
                        srx_stream_t stream);
+/* The same with the gradient of the activation that produced x fused in: din *= act'(x) (x is the post-activation
+ * tensor; mask_act = SRX_ACT_RELU for VGG-19, whose every pooling layer follows a ReLU convolution:
+ * enet/enet/model_vgg.py:11-36).  Same bits as srx_maxpool2x2_bwd followed by srx_act_bwd, one pass instead of two. */
+int srx_maxpool2x2_bwd_masked(const float* x, const float* dout, float* din, int N, int H, int W, int C, int mask_act,
+                              srx_stream_t stream);
 
 /* out[n,i,j,:] = in[n,2i+oy,2j+ox,:] ([N,H,W,C] -> [N,H/2,W/2,C]; H, W even, C % 4 == 0), and its gradient (zero
  * stuffing): din[n,h,w,:] = (h%2==oy && w%2==ox) ? dout[n,h/2,w/2,:] : 0.

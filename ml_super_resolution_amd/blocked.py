@@ -16,8 +16,10 @@ convert to and from TensorFlow's [3, 3, Cin, Cout] for checkpoints and tests.
             srx_conv2d_bwd_data followed by srx_conv2d_bwd_data_acc per further output block;
   wgrad     dw[ib][ob] = bwd_filter(x[ib], dpre[ob]): independent 64 -> 64 problems, ONE launch over all pairs + one
             reduction (srx_conv3x3_blocked_bwd_filter); dbias from the ib = 0 pairs;
-  stride 2  (TF pads 0 before / 1 after on an even image, model_enet.py:136-146) = the stride-1 layer sampled at the
-            odd positions: srx_subsample2 after the forward, zero stuffing (srx_subsample2_bwd) before the gradients.
+  stride 2  (TF pads 0 before / 1 after on an even image, model_enet.py:136-146).  Layers of <= 64 channels run AT their
+            stride in the forward pass and the filter gradient (srx_conv_desc.stride = 2: a quarter of the MFMA work).
+            Wider layers, and every data gradient, use the identity "= the stride-1 layer sampled at the odd positions":
+            srx_subsample2 after the forward, zero stuffing (srx_subsample2_bwd) before the gradients.
 """
 import os
 
@@ -28,6 +30,9 @@ from . import ops
 # layers wider than 64 channels on rows of <= 64 pixels: ONE launch per layer (srx_conv3x3_blocked) instead of one per
 # block pair; SRX_WIDE=0 keeps the block-pair launches (A/B)
 USE_WIDE = os.environ.get('SRX_WIDE', '1') != '0'
+# stride-2 layers of <= 64 channels at their stride (forward and filter gradient: srx_conv_desc.stride = 2) instead of the
+# stride-1 layer + sample map; SRX_TRUE_STRIDE2=0 for A/B
+TRUE_STRIDE2 = os.environ.get('SRX_TRUE_STRIDE2', '1') != '0'
 
 
 def n_blocks(c):
@@ -111,6 +116,12 @@ class BlockedConv(object):
         """x [CIB, N, H, W, ci] -> y [COB, N, H/stride, W/stride, co] (a new tensor: the caller may keep it)."""
         cib, n, h, w, _ = x.shape
         assert cib == self.cib and x.shape[4] == self.ci
+        if self._true_stride2(h, w):
+            # one block in, one block out: the layer runs at its stride (srx_conv_desc.stride = 2), a quarter of the MFMA
+            # work of the stride-1 layer + sample map
+            y = torch.empty((1, n, h // 2, w // 2, self.co), dtype=torch.float32, device=x.device)
+            ops.conv2d_fwd(x[0], self.w[0, 0], self.b, 'same', self.act, out=y[0], stride=2)
+            return y
         y = torch.empty((self.cob, n, h, w, self.co), dtype=torch.float32, device=x.device)
         if self._wide_ok(w):
             ops.conv3x3_blocked(x, self.w, self.b, self.act, out=y)
@@ -131,6 +142,9 @@ class BlockedConv(object):
                                skip=bufs[(ib + 1) % 2][ob] if ib > 0 else None,
                                post_add_relu=_POST_ACT[self.act] if last else 0, out=dst)
         return self._subsampled(y) if self.stride == 2 else y
+
+    def _true_stride2(self, h, w):
+        return TRUE_STRIDE2 and self.stride == 2 and self.cib == 1 and self.cob == 1 and h % 2 == 0 and w % 2 == 0
 
     def _wide_ok(self, width):
         return (USE_WIDE and (self.cib > 1 or self.cob > 1) and self.ci == 64 and self.co == 64 and
@@ -177,6 +191,14 @@ class BlockedConv(object):
 
     def wgrad(self, x, dpre):
         """Fills self.dw / self.db from the layer input x [CIB, N, H, W, ci] and dpre."""
+        if self._true_stride2(x.shape[2], x.shape[3]):
+            need = max(ops.bwd_filter_workspace_bytes(x[0].shape, self.w[0, 0].shape, 'same', stride=2), 16)
+            ws = self._scratch.get('ws')
+            if ws is None or ws.numel() * 4 < need:
+                ws = self._scratch['ws'] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+            ops.conv2d_bwd_filter(x[0], dpre[0].contiguous(), self.w[0, 0].shape, 'same', dw=self.dw[0, 0], dbias=self.db, workspace=ws,
+                                  stride=2)
+            return
         dp = self._full_res(dpre)
         if self._wide_ok(x.shape[3]) and x.is_contiguous() and dp.is_contiguous() and self.dw.is_contiguous():
             _, n, h, w, _ = x.shape

@@ -51,6 +51,7 @@ struct ConvArgs {
     int* tile_counter;    // dynamic scheduling (two-workgroup kernels): next tile to hand out, preset to gridDim.x; null = static
     int tiles_total, tiles_per_col;   // N*NTX*tiles_per_col tiles of TH rows (the last of a column may be shorter)
     int lds_sched_slot;   // float index in LDS of the 4-byte mailbox used to broadcast the tile index
+    int stride;           // two-workgroup kernels, forward only: 1, or 2 (tiles with their own halo: RS = (TW-1)*2 + KW slots per row)
     int d2s_r, d2s_rc;    // sub-pixel store mode (two-workgroup kernels): r > 1 -> y is [N,OH*r,OW*r,Cout/(r*r)] and channel
                           // ch of LR pixel (h,w) is stored at HR row h*r + ch/rc, column offset w*rc + ch%rc, rc = r*C
 };
@@ -67,6 +68,7 @@ struct WgradArgs {
     float inv_rs;
     int stagger;
     int zero_slot;      // index of a pixel slot past the tile that the kernel keeps zeroed
+    int stride;         // cursor kernel (wgrad_mfma_kernel) only: 1, or 2 (output pixel (r, c) reads the tile at (2r, 2c))
     unsigned long long* trace;  // diagnostic build (-DSRX_TRACE) only: per-wave cycle stamps
 };
 
@@ -493,7 +495,7 @@ __device__ __forceinline__ void conv_group(const float* lds, const float (&wr)[K
         const int tt = live ? t : 0;
         const int orow = fdiv_small(tt, inv_tw, tw);
         const int ocol = tt - orow * tw;
-        laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        laddr[i] = ((orow * a.RS + ocol) * PS << (a.stride - 1)) + ((CINP >= 16) ? 4 * kq : kq);   // (stride 2: tile position (2 orow, 2 ocol))
         // (sub-pixel store mode: the offset of HR pixel (h*r, w*r), channel 0 -- conv_epilogue adds the channel part)
         off[i] = !valid[i] ? 0u
                  : (a.d2s_r ? (unsigned)(((h + orow) * a.d2s_r * a.OW + ow0 + ocol) * a.d2s_rc)
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
         }
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
-        const int n_need = (th + KH - 1) * a.RS + (KW - 1);
+        const int n_need = ((th - 1) * a.stride + KH) * a.RS + (KW - 1);
         [[maybe_unused]] const bool first_tile = dyn ? (tile == (int)blockIdx.x) : (u == u0);
 
         const unsigned long long ts_stage = SRX_STAMP();
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(const ConvArgs a) 
 #ifdef SRX_TRACE
         if (!(a.dbg & 1) || first_tile)                       // diagnostic builds: stage only the first tile
 #endif
-            stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
+            stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h * a.stride - a.pad_t, ow0 * a.stride - a.pad_l, a.RS, a.inv_rs, n_need, tid);
         const unsigned long long ts_ld = SRX_STAMP();
         lds_barrier();
         const int next_tile = dyn ? *mailbox : 0;
@@ -1420,7 +1422,7 @@ __device__ __forceinline__ void conv_group_generic(const float* lds, const f32x4
         const int tt = (t < npx) ? t : 0;
         const int orow = fdiv_small(tt, inv_tw, tw);
         const int ocol = tt - orow * tw;
-        laddr[i] = (orow * a.RS + ocol) * PS + ((CINP >= 16) ? 4 * kq : kq);
+        laddr[i] = ((orow * a.RS + ocol) * PS << (a.stride - 1)) + ((CINP >= 16) ? 4 * kq : kq);   // (stride 2: tile position (2 orow, 2 ocol))
         // (sub-pixel store mode: the offset of HR pixel (h*r, w*r), channel 0 -- conv_epilogue adds the channel part)
         off[i] = !valid[i] ? 0u
                  : (a.d2s_r ? (unsigned)(((h + orow) * a.d2s_r * a.OW + ow0 + ocol) * a.d2s_rc)
@@ -1501,9 +1503,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_generic_kernel(const ConvArg
         if (u1 - u < th) th = u1 - u;
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
-        const int n_need = (th + KH - 1) * a.RS + (KW - 1);
+        const int n_need = ((th - 1) * a.stride + KH) * a.RS + (KW - 1);
         lds_barrier();
-        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
+        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h * a.stride - a.pad_t, ow0 * a.stride - a.pad_l, a.RS, a.inv_rs, n_need, tid);
         lds_barrier();
         const int n_sub = (th * tw + 15) >> 4;
         const float inv_tw = 1.0f / (float)tw;
@@ -1593,16 +1595,16 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
         if (u1 - u < th) th = u1 - u;
         const int ow0 = tx * a.TW;
         const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
-        const int n_need = (th + KH - 1) * a.RS + (KW - 1);
+        const int n_need = ((th - 1) * a.stride + KH) * a.RS + (KW - 1);
 
         lds_barrier();
-        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
+        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h * a.stride - a.pad_t, ow0 * a.stride - a.pad_l, a.RS, a.inv_rs, n_need, tid);
         lds_barrier();
 
         const int npx = th * tw;
         const int nsteps = (npx + 3) >> 2;
         const float* dbase = a.dpre + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout + co_c;  // + 32-bit offsets
-        const int x_step = 4 * PS, x_wrap = (a.RS - tw) * PS;
+        const int x_step = 4 * PS * a.stride, x_wrap = (a.RS - tw) * PS * a.stride;   // (stride 2: pixel (r, c) sits at tile slot (2r, 2c))
         const int b_step = 4 * a.Cout, b_wrap = (a.OW - tw) * a.Cout;
 
         auto advance = [&](WgCursor& cu) {
@@ -1621,7 +1623,7 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
         {
             const int r0 = fdiv_small(kq < npx ? kq : 0, 1.0f / (float)tw, tw);
             cur.p = kq; cur.c = (kq < npx ? kq : 0) - r0 * tw;
-            cur.xaddr = (r0 * a.RS + cur.c) * PS; cur.boff = (r0 * a.OW + cur.c) * a.Cout;
+            cur.xaddr = (r0 * a.RS + cur.c) * PS * a.stride; cur.boff = (r0 * a.OW + cur.c) * a.Cout;
         }
         WgCursor pf = cur;                      // dpre prefetch cursor, 3 steps ahead
         float bq[3];

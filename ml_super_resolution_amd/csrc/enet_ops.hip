@@ -47,8 +47,12 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const f32x4* __restri
     }
 }
 
+// mask_act != ACT_NONE: the gradient of the activation that PRODUCED x rides along (din *= act'(x), x being the
+// post-activation tensor): the ReluGrad that follows every pooling gradient in VGG-19's backward pass costs no launch
+// and no extra pass over the tensor -- the kernel has x in registers to find the arg-max anyway.
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dout,
-                                                           f32x4* __restrict__ din, int N, int H, int W, int C4, int OH, int OW) {
+                                                           f32x4* __restrict__ din, int N, int H, int W, int C4, int OH, int OW,
+                                                           int mask_act) {
     const size_t total = (size_t)N * H * W * C4;
     SRX_GRID_STRIDE(i, total) {
         const int c = (int)(i % C4);
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const f32x4* __restri
             for (int k = 1; k < 4; ++k)
                 if (in_img[k] && v[k][e] > best) { best = v[k][e]; arg = k; }
             r[e] = (arg == me) ? g[e] : 0.f;
+            if (mask_act) r[e] *= act_grad_from_y(v[me][e], mask_act);
         }
         din[i] = r;
     }
@@ -492,13 +497,18 @@ int srx_maxpool2x2(const float* in, float* out, int N, int H, int W, int C, srx_
     SRX_LAUNCHED("maxpool");
 }
 
-int srx_maxpool2x2_bwd(const float* x, const float* dout, float* din, int N, int H, int W, int C, srx_stream_t stream) {
+int srx_maxpool2x2_bwd_masked(const float* x, const float* dout, float* din, int N, int H, int W, int C, int mask_act, srx_stream_t stream) {
+    if (mask_act < SRX_ACT_NONE || mask_act > SRX_ACT_SIGMOID) return set_error(SRX_ERR_BAD_ARG, "bad mask_act");
     if (!x || !dout || !din) return set_error(SRX_ERR_BAD_ARG, "null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return set_error(SRX_ERR_BAD_ARG, "maxpool: bad dims (C must be a multiple of 4)");
     if (!al16(x) || !al16(dout) || !al16(din)) return set_error(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       (const f32x4*)x, (const f32x4*)dout, (f32x4*)din, N, H, W, C / 4, (H + 1) / 2, (W + 1) / 2);
+                       (const f32x4*)x, (const f32x4*)dout, (f32x4*)din, N, H, W, C / 4, (H + 1) / 2, (W + 1) / 2, mask_act);
     SRX_LAUNCHED("maxpool_bwd");
+}
+
+int srx_maxpool2x2_bwd(const float* x, const float* dout, float* din, int N, int H, int W, int C, srx_stream_t stream) {
+    return srx_maxpool2x2_bwd_masked(x, dout, din, N, H, W, C, SRX_ACT_NONE, stream);
 }
 
 int srx_subsample2(const float* in, float* out, int N, int H, int W, int C, int oy, int ox, srx_stream_t stream) {

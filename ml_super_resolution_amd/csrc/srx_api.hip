@@ -208,7 +208,8 @@ int check_desc(const srx_conv_desc* d) {
     if (!d) return fail(SRX_ERR_BAD_ARG, "null descriptor");
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0)
         return fail(SRX_ERR_BAD_ARG, "non-positive dimension in descriptor");
-    if (d->stride != 1) return fail(SRX_ERR_UNSUPPORTED, "stride %d: only stride 1 is implemented", d->stride);
+    if (d->stride != 1 && d->stride != 2) return fail(SRX_ERR_UNSUPPORTED, "stride %d: strides 1 and 2 are implemented", d->stride);
+    if (d->stride == 2 && d->subpixel_r > 1) return fail(SRX_ERR_UNSUPPORTED, "stride 2 with the sub-pixel store is not implemented");
     if (d->pad_mode != SRX_PAD_SAME && d->pad_mode != SRX_PAD_VALID) return fail(SRX_ERR_BAD_ARG, "bad pad_mode");
     if (d->act < SRX_ACT_NONE || d->act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad activation");
     if (d->post_add_relu != 0 && d->post_add_relu != SRX_ACT_RELU && d->post_add_relu != SRX_ACT_LRELU)
@@ -226,12 +227,59 @@ int check_desc(const srx_conv_desc* d) {
     return SRX_OK;
 }
 
+// TensorFlow's geometry: SAME: out = ceil(in / s), pad_total = max((out - 1) s + k - in, 0), pad_before = pad_total / 2
+// (the odd one goes AFTER: a stride-2 3x3 layer on an even-sized image pads 0 before / 1 after,
+// enet/enet/model_enet.py:136-146; on an odd-sized one 1 / 1).  VALID: out = (in - k) / s + 1.
 void geometry(const srx_conv_desc* d, int* pad_t, int* pad_l, int* OH, int* OW) {
+    const int s = d->stride;
     if (d->pad_mode == SRX_PAD_SAME) {
-        *pad_t = (d->KH - 1) / 2; *pad_l = (d->KW - 1) / 2; *OH = d->H; *OW = d->W;
+        *OH = (d->H + s - 1) / s; *OW = (d->W + s - 1) / s;
+        const int ph = (*OH - 1) * s + d->KH - d->H, pw = (*OW - 1) * s + d->KW - d->W;
+        *pad_t = (ph > 0 ? ph : 0) / 2; *pad_l = (pw > 0 ? pw : 0) / 2;
     } else {
-        *pad_t = 0; *pad_l = 0; *OH = d->H - d->KH + 1; *OW = d->W - d->KW + 1;
+        *pad_t = 0; *pad_l = 0; *OH = (d->H - d->KH) / s + 1; *OW = (d->W - d->KW) / s + 1;
     }
+}
+
+// Stride 2 (forward and filter gradient on the two-workgroup kernels): every tile carries its own halo -- RS = (TW - 1) 2 +
+// KW slots per tile row, (TH - 1) 2 + KH rows -- and output pixel (r, c) of a tile reads its window at tile slot (2r, 2c).
+// Picks the column width that puts the most output pixels into the 80-KiB tile.
+int make_plan_s2(int N, int H, int W, int OH, int OW, int in_c, int out_c, int KH, int KW, int pad_t, int pad_l, Plan* p) {
+    p->KH = KH; p->KW = KW;
+    p->cinp = pad_channels(in_c);
+    p->nch = chunks_for(out_c);
+    if (p->cinp < 0 || p->nch < 0)
+        return fail(SRX_ERR_UNSUPPORTED, "channel counts %d->%d outside the kernel set (<=64)", in_c, out_c);
+    p->pad_t = pad_t; p->pad_l = pad_l; p->OH = OH; p->OW = OW;
+    const size_t slot_bytes = (size_t)((p->cinp == 4) ? 4 : p->cinp + 4) * 4;
+    const long max_slots = (long)(kLdsBudget / slot_bytes) - 8;     // (the cursor wgrad kernel keeps a zeroed slot behind the tile)
+    int best_tw = 0, best_th = 0;
+    long best_px = 0;
+    for (int TW = 32; TW >= 4; TW >>= 1) {
+        const int tw = TW < OW ? TW : OW;
+        const long RS = (long)(tw - 1) * 2 + KW;
+        long rows = (max_slots - (KW - 1)) / RS;                 // tile rows that fit
+        long th = (rows - KH) / 2 + 1;
+        if (rows < KH || th < 1) continue;
+        if (th > OH) th = OH;
+        if (th > 16) th = 16;
+        const long px = th * tw;
+        if (px > best_px) { best_px = px; best_tw = tw; best_th = (int)th; }
+        if (TW >= OW && TW > 4) continue;
+    }
+    if (!best_px) return fail(SRX_ERR_UNSUPPORTED, "filter %dx%d at stride 2 too large for the LDS tile", KH, KW);
+    p->TW = best_tw; p->TH = best_th;
+    p->NTX = (OW + best_tw - 1) / best_tw;
+    p->RS = (best_tw - 1) * 2 + KW;
+    const long rows_total = (long)N * p->NTX * OH;
+    if (rows_total >= (1L << 31)) return fail(SRX_ERR_UNSUPPORTED, "too many rows for 32-bit unit indexing");
+    p->units_total = (int)rows_total;
+    long g = rows_total / p->TH;
+    if (g < 1) g = 1;
+    const int kMaxGrid = max_grid();
+    p->grid = (int)(g < kMaxGrid ? g : kMaxGrid);
+    p->lds_bytes = ((size_t)((p->TH - 1) * 2 + KH) * p->RS + (KW - 1)) * slot_bytes;
+    return SRX_OK;
 }
 
 size_t part_stride(const srx_conv_desc* d) {
@@ -253,7 +301,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // mirror case, 3 -> 64 channels, was tried the same way and lost to the MFMA kernel: 56 vs 48 us.)
     // SRX_NARROW=0 keeps them on the MFMA kernels (A/B).
     {
-        if (knobs().narrow && !a.d2s_r && launch_conv_narrow(k, a, s, &err)) {
+        if (knobs().narrow && !a.d2s_r && a.stride == 1 && launch_conv_narrow(k, a, s, &err)) {
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
@@ -267,12 +315,12 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
                         (!a.mask || (a.mask_act == ACT_RELU && a.act == ACT_NONE && !a.post_relu));
     // (p.RS == W + pad_l: the only pad slots of a tile row are the pad_l leading ones, which the scalar staging
     // never writes; a dgrad of a VALID layer has trailing pad slots inside the row as well and stays on path 0)
-    const bool pipe_ok = epi_ok && !a.d2s_r && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
+    const bool pipe_ok = epi_ok && !a.d2s_r && a.stride == 1 && a.Cin == p.cinp && p.NTX == 1 && p.RS >= ppp && p.RS == a.W + a.pad_l &&
                          16 * npart <= a.OW && (a.Cout & 3) == 0 &&
                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     // Column-strip variant (images too wide for full-width tiles): strips of 16 or 32 columns no wider than the
     // image, one sub-tile sequence per workgroup (64 output channels); any padding.
-    const bool strip_ok = epi_ok && !a.d2s_r && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
+    const bool strip_ok = epi_ok && !a.d2s_r && a.stride == 1 && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
                           p.RS >= ppp && npart == 1 && (a.Cout & 3) == 0 &&
                           a.y != a.skip && a.y != a.mask &&   // (the columns two strips share are computed twice: no in-place epilogue operand)
                           (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
@@ -341,6 +389,7 @@ void fill_conv_args(ConvArgs* a, const Plan& p, int N, int H, int W, int in_c, i
     a->TH = p.TH; a->TW = p.TW; a->NTX = p.NTX; a->RS = p.RS;
     a->units_total = p.units_total;
     a->inv_rs = 1.0f / (float)p.RS;
+    a->stride = 1;
     a->stagger = stagger_sleeps(p);
     a->dbg = knobs().dbg;        // both zero / null unless built with -DSRX_TRACE
     a->trace = knobs().trace;
@@ -364,7 +413,8 @@ size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op) {
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
-    if (make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p) != SRX_OK) return 0;
+    if ((d->stride == 2 ? make_plan_s2(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p)
+                        : make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p)) != SRX_OK) return 0;
     return (size_t)p.grid * part_stride(d) * sizeof(float);
 }
 
@@ -378,14 +428,16 @@ int srx_conv2d_fwd(const srx_conv_desc* d, const float* x, const float* w, const
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
-    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p,
-                   d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU);
+    if (d->stride == 2) rc = make_plan_s2(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
+    else rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p,
+                        d->act == SRX_ACT_NONE || d->act == SRX_ACT_RELU);
     if (rc) return rc;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.mask = nullptr; a.y = y;
     fill_conv_args(&a, p, d->N, d->H, d->W, d->Cin, d->Cout);
     a.act = d->act; a.post_relu = d->post_add_relu; a.mask_act = 0;
+    a.stride = d->stride;
     if (d->subpixel_r > 1) {
         // the store goes through the depth-to-space map: y is [N, OH*r, OW*r, Cout/(r*r)]
         if (skip) return fail(SRX_ERR_UNSUPPORTED, "subpixel_r with a skip operand is not implemented");
@@ -417,6 +469,9 @@ static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float*
     if (!aligned16(dpre) || !aligned16(w) || !aligned16(dx_out) || (x_in && !aligned16(x_in)) || (dx_acc && !aligned16(dx_acc)))
         return fail(SRX_ERR_ALIGN, "tensor base pointers must be 16-byte aligned");
     if (in_act < SRX_ACT_NONE || in_act > SRX_ACT_SIGMOID) return fail(SRX_ERR_BAD_ARG, "bad in_act");
+    if (d->stride != 1)
+        return fail(SRX_ERR_UNSUPPORTED, "bwd_data at stride %d: the data gradient of a stride-2 layer is the stride-1 data gradient of the "
+                                         "zero-stuffed upstream gradient (srx_subsample2_bwd, then this entry point with stride 1)", d->stride);
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     // the kernel stages dpre [N,OH,OW,Cout] and produces dx [N,H,W,Cin]; full-correlation padding
@@ -431,6 +486,19 @@ static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float*
     return dispatch_conv(p, true, a, (hipStream_t)stream, ws, ws_bytes);
 }
 
+// The linear-walk filter-gradient kernels keep 4 zeroed slots behind the tile (their last step may read past it): a
+// plan whose tile fills the 80-KiB budget to the last slot (32-wide rows, 64 channels: 7 + 2 rows of 33 slots) would send
+// the layer to the cursor kernel (58 us instead of ~40 at 64 x 32 x 32, the EnhanceNet generator's residual blocks).
+// One row less and it fits.  The grid (= number of partial filters = workspace size) does not depend on the tile height.
+static void wgrad_tile_for_linear_walk(const srx_conv_desc* d, Plan* p) {
+    if (p->NTX != 1 || !knobs().wgrad_lin) return;
+    const size_t slot_bytes = (size_t)((p->cinp == 4) ? 4 : p->cinp + 4) * 4;
+    while (p->TH > 1 && p->lds_bytes + 4 * slot_bytes > 80 * 1024) {
+        p->TH -= 1;
+        p->lds_bytes = ((size_t)(p->TH + d->KH - 1) * p->RS + (d->KW - 1)) * slot_bytes;
+    }
+}
+
 int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const float* dpre, void* ws, size_t ws_bytes,
                                    int* n_partials, srx_stream_t stream) {
     int rc = check_desc(d);
@@ -440,8 +508,11 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     int pt, pl, OH, OW;
     geometry(d, &pt, &pl, &OH, &OW);
     Plan p;
-    rc = make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
+    const bool s2 = d->stride == 2;
+    rc = s2 ? make_plan_s2(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p)
+            : make_plan(d->N, d->H, d->W, OH, OW, d->Cin, d->Cout, d->KH, d->KW, pt, pl, &p);
     if (rc) return rc;
+    if (!s2) wgrad_tile_for_linear_walk(d, &p);
     const size_t need = (size_t)p.grid * part_stride(d) * sizeof(float);
     if (!ws || ws_bytes < need)
         return fail(SRX_ERR_WORKSPACE, "bwd_filter needs %zu workspace bytes, got %zu", need, ws_bytes);
@@ -455,14 +526,15 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     a.pad_t = pt; a.pad_l = pl; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
     a.stagger = stagger_sleeps(p);
-    a.zero_slot = (p.TH + d->KH - 1) * p.RS + (d->KW - 1);      // first slot after the largest tile
+    a.stride = d->stride;
+    a.zero_slot = ((p.TH - 1) * d->stride + d->KH) * p.RS + (d->KW - 1);      // first slot after the largest tile
     a.trace = knobs().trace;   // diagnostic builds only
     const size_t wg_lds = p.lds_bytes + (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     ConvKey k{d->KH, d->KW, p.cinp, p.nch, false};
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
     // Linear-walk kernel for full-width tiles (see wgrad_lin_kernel); SRX_WGRAD_LIN=0 selects the cursor kernel (A/B).
-    const int use_lin = knobs().wgrad_lin;
+    const int use_lin = knobs().wgrad_lin && !s2;       // (stride 2: the cursor kernel, whose pixel cursor simply steps two slots)
     const int kPipeGrid = pipe_grid();
     const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && p.RS == d->W + pl && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
@@ -497,7 +569,7 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     }
     {
         // 64 <-> 3 channel layers: 16 lanes per position, no MFMA (conv_narrow.hip); SRX_NARROW=0 for A/B
-        if (!wdone && knobs().narrow) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
+        if (!wdone && knobs().narrow && !s2) wdone = launch_wgrad_narrow(k, a, p.grid, s, &err);
     }
     // column strips: exact-fit channels and a tile row of at least one staging pass (the strip stager is the scalar one)
     // (and every strip, the narrower last one included, at least one 4-position step wide: the lanes of a step that
@@ -613,6 +685,7 @@ int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw,
     a.pad_t = 1; a.pad_l = 1; a.TH = p.TH; a.TW = p.TW; a.NTX = p.NTX; a.RS = p.RS;
     a.units_total = p.units_total; a.inv_rs = 1.0f / (float)p.RS;
     a.stagger = 0;
+    a.stride = 1;
     a.zero_slot = (p.TH + 2) * p.RS + 2;
     a.trace = nullptr;
     q.x_pair_stride = (long)blk; q.d_pair_stride = (long)blk;

@@ -131,8 +131,11 @@ class Vgg19(object):
                 dx = torch.empty_like(below)
                 cb, n, h, w, c = below.shape
                 g = g.contiguous()
-                ops.maxpool2x2_bwd(below.view(cb * n, h, w, c), g.view(cb * n, g.shape[2], g.shape[3], c), out=dx.view(cb * n, h, w, c))
-                g, masked = dx, False
+                # (every pooling layer of VGG-19 follows a ReLU convolution: its ReluGrad rides in the pooling gradient)
+                fuse = 'conv' in below_name
+                ops.maxpool2x2_bwd(below.view(cb * n, h, w, c), g.view(cb * n, g.shape[2], g.shape[3], c), out=dx.view(cb * n, h, w, c),
+                                   mask_act='relu' if fuse else None)
+                g, masked = dx, fuse
             else:
                 dpre = g if masked else relu_grad(g, feats[name])
                 # the ReluGrad of the conv layer below rides in this layer's data-gradient launch

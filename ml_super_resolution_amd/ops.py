@@ -27,19 +27,21 @@ def _chk(t, name):
         raise ValueError('%s lives on %s but the current device is cuda:%d' % (name, t.device, torch.cuda.current_device()))
 
 
-def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False, subpixel_r=0):
+def conv_desc(x_shape, w_shape, padding='same', act=None, post_add_relu=False, subpixel_r=0, stride=1):
     N, H, W, Cin = x_shape
     KH, KW, wci, Cout = w_shape
     if wci != Cin:
         raise ValueError('filter Cin %d != input channels %d' % (wci, Cin))
-    return ConvDesc(N, H, W, Cin, Cout, KH, KW, 1, PAD_BY_NAME[padding.lower()],
+    return ConvDesc(N, H, W, Cin, Cout, KH, KW, int(stride), PAD_BY_NAME[padding.lower()],
                     ACT_BY_NAME[act] if not isinstance(act, int) else act, int(post_add_relu), 0, int(subpixel_r))
 
 
 def out_shape(d):
+    """TensorFlow's geometry: SAME ceil(in / stride); VALID (in - k) / stride + 1."""
+    s = d.stride
     if d.pad_mode == _lib.PAD_SAME:
-        return (d.N, d.H, d.W, d.Cout)
-    return (d.N, d.H - d.KH + 1, d.W - d.KW + 1, d.Cout)
+        return (d.N, (d.H + s - 1) // s, (d.W + s - 1) // s, d.Cout)
+    return (d.N, (d.H - d.KH) // s + 1, (d.W - d.KW) // s + 1, d.Cout)
 
 
 _scratch = {}
@@ -63,12 +65,13 @@ def reduce_scratch(device):
     return _scratch[key]
 
 
-def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_relu=False, out=None, subpixel_r=0):
+def conv2d_fwd(x, w, bias=None, padding='same', act=None, skip=None, post_add_relu=False, out=None, subpixel_r=0, stride=1):
     """act(bias + x (*) w) [+ skip] [relu] -- srx_conv2d_fwd.  subpixel_r > 1: the result is stored through the
-    depth-to-space map, [N,OH*r,OW*r,Cout/r^2] (bit-identical to conv2d_fwd + depth_to_space, one launch)."""
+    depth-to-space map, [N,OH*r,OW*r,Cout/r^2] (bit-identical to conv2d_fwd + depth_to_space, one launch).
+    stride 1 or 2 (tf.layers.conv2d(strides=2, padding='same'): enet/enet/model_enet.py:136-146)."""
     for t, n in ((x, 'x'), (w, 'w'), (bias, 'bias'), (skip, 'skip')):
         _chk(t, n)
-    d = conv_desc(x.shape, w.shape, padding, act, post_add_relu, subpixel_r)
+    d = conv_desc(x.shape, w.shape, padding, act, post_add_relu, subpixel_r, stride)
     shape = out_shape(d)
     if subpixel_r > 1:
         r = int(subpixel_r)
@@ -96,17 +99,19 @@ def conv2d_bwd_data(dpre, w, x_shape, padding='same', x_in=None, in_act=None, ou
     return dx
 
 
-def bwd_filter_workspace_bytes(x_shape, w_shape, padding='same'):
-    d = conv_desc(x_shape, w_shape, padding)
+def bwd_filter_workspace_bytes(x_shape, w_shape, padding='same', stride=1):
+    d = conv_desc(x_shape, w_shape, padding, stride=stride)
     return lib().srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_BWD_FILTER)
 
 
 def conv2d_bwd_filter(x, dpre, w_shape, padding='same', w_for_decay=None, wd_scale=0.0, dw=None, dbias=None,
-                      want_dbias=True, workspace=None):
-    """(dw, dbias) -- srx_conv2d_bwd_filter."""
+                      want_dbias=True, workspace=None, stride=1):
+    """(dw, dbias) -- srx_conv2d_bwd_filter.  stride 2: dpre is the gradient at the layer's (half-resolution) output."""
     for t, n in ((x, 'x'), (dpre, 'dpre'), (w_for_decay, 'w_for_decay')):
         _chk(t, n)
-    d = conv_desc(x.shape, w_shape, padding)
+    d = conv_desc(x.shape, w_shape, padding, stride=stride)
+    if tuple(dpre.shape) != tuple(out_shape(d)):
+        raise ValueError('dpre has shape %s, the layer output is %s' % (tuple(dpre.shape), tuple(out_shape(d))))
     if dw is None:
         dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     if dbias is None and want_dbias:
@@ -497,11 +502,14 @@ def maxpool2x2(x, out=None):
     return out
 
 
-def maxpool2x2_bwd(x, dout, out=None):
+def maxpool2x2_bwd(x, dout, out=None, mask_act=None):
+    """Gradient of 2x2 / 2 SAME max-pooling w.r.t. its input x; mask_act: also multiply by act'(x), the gradient of the
+    activation that produced x (one pass instead of maxpool2x2_bwd + act_bwd, same bits)."""
     _chk(x, 'x'); _chk(dout, 'dout')
     N, H, W, C = x.shape
     out = out if out is not None else torch.empty_like(x)
-    check(lib().srx_maxpool2x2_bwd(_ptr(x), _ptr(dout), _ptr(out), N, H, W, C, _stream()), 'srx_maxpool2x2_bwd')
+    check(lib().srx_maxpool2x2_bwd_masked(_ptr(x), _ptr(dout), _ptr(out), N, H, W, C, ACT_BY_NAME[mask_act], _stream()),
+          'srx_maxpool2x2_bwd_masked')
     return out
 
 

@@ -37,6 +37,11 @@ def test_maxpool_fwd_bwd(shape):
     # ties (post-ReLU zeros): the first maximum in scan order takes the gradient
     xz = np.maximum(x, 0) * (rng.uniform(size=shape) > 0.5)
     np.testing.assert_array_equal(_np(ops.maxpool2x2_bwd(dev(xz), dev(dy))), E.maxpool2x2_bwd(xz, dy).astype(np.float32))
+    # the activation gradient of the layer that produced x fused in: the same bits as the two launches
+    for act in ('relu', 'lrelu', 'tanh'):
+        xa = np.tanh(x) if act == 'tanh' else xz if act == 'relu' else x
+        two = ops.act_bwd(ops.maxpool2x2_bwd(dev(xa), dev(dy)), dev(xa), act)
+        assert torch.equal(ops.maxpool2x2_bwd(dev(xa), dev(dy), mask_act=act), two)
 
 
 def test_subsample_blocks_patches_are_exact_permutations():

@@ -382,3 +382,67 @@ def test_bwd_filter_in_two_calls_is_the_same(ops):
         dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
         ops.conv2d_bwd_filter_reduce(x.shape, wshape, pad, ws, n, dw2, db2, w_for_decay=w, wd_scale=1e-4)
         assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+STRIDE2 = [
+    # (N, H, W, k, cin, cout, pad, act): even sizes (TF pads 0 before / 1 after), odd sizes (1 / 1), both mixed, VALID,
+    # the discriminator's stride-2 layers of <= 64 channels at their sizes (enet/enet/model_enet.py:136-146), tiles
+    # that do not divide the output, one-pixel outputs, RGB in
+    (2, 16, 16, 3, 32, 32, 'SAME', 'lrelu'), (3, 17, 15, 3, 32, 32, 'SAME', 'lrelu'), (2, 128, 128, 3, 32, 32, 'SAME', 'lrelu'),
+    (2, 64, 64, 3, 64, 64, 'SAME', 'lrelu'), (1, 21, 40, 3, 64, 64, 'SAME', 'relu'), (2, 9, 11, 3, 64, 32, 'VALID', None),
+    (1, 2, 2, 3, 64, 64, 'SAME', None), (1, 3, 3, 3, 32, 64, 'VALID', 'relu'), (2, 30, 70, 3, 3, 32, 'SAME', 'lrelu'),
+    (1, 37, 37, 3, 64, 48, 'SAME', None), (2, 12, 12, 5, 32, 3, 'SAME', 'tanh'), (1, 50, 6, 1, 64, 64, 'SAME', None),
+]
+
+
+@pytest.mark.parametrize('shape', STRIDE2, ids=['%dx%dx%d_k%d_%d-%d_%s' % s[:7] for s in STRIDE2])
+def test_stride2_forward_and_filter_gradient_vs_oracle(shape, ops):
+    """srx_conv_desc.stride = 2 (tf.layers.conv2d(strides=2): TensorFlow's SAME geometry out = ceil(in / 2), the odd
+    padding pixel AFTER): forward and filter / bias gradient through the C ABI against the oracle's strided
+    convolution, and against the identity the wide layers still use (stride-1 layer sampled at the odd positions) on
+    even sizes."""
+    from oracle import oracle_enet as E
+    N, H, W, k, cin, cout, pad, act = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+    y = ops.conv2d_fwd(dev(x), dev(w), dev(b), pad, act, stride=2)
+    if pad == 'SAME':
+        ref_pre = E.conv2d_same_fwd(x, w, b, 2)
+    else:
+        ref_pre = O.conv2d_fwd(x, w, b, 'VALID')[:, ::2, ::2]
+    assert tuple(y.shape) == ref_pre.shape
+    close(y, O.act_apply(ref_pre, act))
+    if pad == 'SAME' and k == 3 and H % 2 == 0 and W % 2 == 0:
+        full = ops.conv2d_fwd(dev(x), dev(w), dev(b), pad, act)
+        assert torch.equal(y, full[:, 1::2, 1::2].contiguous())            # the same products in the same order
+    dpre = rng.normal(size=ref_pre.shape).astype(np.float32)
+    dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), w.shape, pad, stride=2)
+    if pad == 'SAME':
+        _, dw_ref, db_ref = E.conv2d_same_bwd(x, w, dpre, 2, want_dx=False)
+    else:
+        stuffed = np.zeros((N, H - k + 1, W - k + 1, cout), np.float32)
+        stuffed[:, ::2, ::2] = dpre
+        dw_ref, db_ref = O.conv2d_bwd_filter(x, stuffed, (k, k), 'VALID')
+    close(dw, dw_ref)
+    close(db, db_ref)
+    # deterministic
+    dw2, db2 = ops.conv2d_bwd_filter(dev(x), dev(dpre), w.shape, pad, stride=2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_stride2_argument_errors(ops):
+    from ml_super_resolution_amd._lib import SrxError
+    x = torch.zeros((1, 8, 8, 64), device='cuda')
+    w = torch.zeros((3, 3, 64, 64), device='cuda')
+    with pytest.raises(SrxError, match='stride 3'):
+        ops.conv2d_fwd(x, w, None, 'same', None, stride=3)
+    with pytest.raises(ValueError, match='dpre has shape'):
+        ops.conv2d_bwd_filter(x, torch.zeros((1, 8, 8, 64), device='cuda'), w.shape, 'same', stride=2)
+    # the data gradient at stride 2 is composed (zero stuffing + stride-1 data gradient): the entry point says so
+    import ctypes
+    from ml_super_resolution_amd import _lib
+    d = ops.conv_desc(x.shape, w.shape, 'same', stride=2)
+    rc = _lib.lib().srx_conv2d_bwd_data(ctypes.byref(d), None, None, None, 0, None, None, 0, None)
+    assert rc != 0
