@@ -31,7 +31,7 @@ typedef void* srx_stream_t; /* hipStream_t */
 typedef enum {
     SRX_OK = 0,
     SRX_ERR_BAD_ARG = -1,     /* null pointer, non-positive dim, unknown enum */
-    SRX_ERR_UNSUPPORTED = -2, /* shape outside the compiled kernel set (e.g. stride != 1) */
+    SRX_ERR_UNSUPPORTED = -2, /* shape outside the compiled kernel set (e.g. stride 3, a stride-2 data gradient) */
     SRX_ERR_WORKSPACE = -3,   /* workspace missing or too small */
     SRX_ERR_LAUNCH = -4,      /* HIP runtime reported an error at launch */
     SRX_ERR_ALIGN = -5        /* pointer not 16-byte aligned */
@@ -49,14 +49,19 @@ typedef enum {
 
 typedef enum { SRX_OP_FWD = 0, SRX_OP_BWD_DATA = 1, SRX_OP_BWD_FILTER = 2 } srx_conv_op;
 
-/* One stride-1 convolution layer.  N,H,W,Cin describe the layer INPUT x; the output
- * is [N,OH,OW,Cout] with OH,OW from pad_mode (TF semantics: SAME -> OH=H, pad_before =
- * (K-1)/2; VALID -> OH = H-KH+1). */
+/* One convolution layer.  N,H,W,Cin describe the layer INPUT x; the output is [N,OH,OW,Cout] with OH,OW from
+ * pad_mode and stride, TensorFlow's geometry: SAME -> OH = ceil(H / stride), pad_total = max((OH-1) stride + KH - H, 0),
+ * pad_before = pad_total / 2 (the odd pixel goes AFTER); VALID -> OH = (H - KH) / stride + 1. */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, KW;
-    int32_t stride;        /* must be 1.  (A stride-2 SAME 3x3 layer on an even-sized image -- ENet's discriminator,
-                            * enet/enet/model_enet.py:136-146 -- is the stride-1 layer sampled at the odd positions:
-                            * srx_subsample2 / srx_subsample2_bwd below.) */
+    int32_t stride;        /* 1, or 2: tf.layers.conv2d(strides=2, padding='same') of ENet's discriminator
+                            * (enet/enet/model_enet.py:136-146; 0 before / 1 after on an even-sized image).  Stride 2 is
+                            * implemented by srx_conv2d_fwd and srx_conv2d_bwd_filter (+ _partials / _reduce / the
+                            * workspace query; there dpre is the gradient at the half-resolution output), at a quarter of
+                            * the stride-1 layer's MFMA work.  srx_conv2d_bwd_data(_acc) refuses it: the data gradient of
+                            * a stride-2 layer is the stride-1 data gradient of the zero-stuffed upstream gradient
+                            * (srx_subsample2_bwd below), and srx_conv3x3_blocked (> 64 channels) is stride 1: the
+                            * stride-1 layer sampled at the odd positions (srx_subsample2). */
     int32_t pad_mode;      /* srx_pad_mode */
     int32_t act;           /* srx_act fused after bias */
     int32_t post_add_relu; /* activation applied AFTER the skip add: 0 none, SRX_ACT_RELU (1) relu(conv + skip) as in

@@ -488,8 +488,8 @@ static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float*
 
 // The linear-walk filter-gradient kernels keep 4 zeroed slots behind the tile (their last step may read past it): a
 // plan whose tile fills the 80-KiB budget to the last slot (32-wide rows, 64 channels: 7 + 2 rows of 33 slots) would send
-// the layer to the cursor kernel (58 us instead of ~40 at 64 x 32 x 32, the EnhanceNet generator's residual blocks).
-// One row less and it fits.  The grid (= number of partial filters = workspace size) does not depend on the tile height.
+// the layer to the cursor kernel (the EnhanceNet generator's residual blocks at 64 x 32 x 32; at that size either kernel
+// takes 58 us -- the launch is latency-bound -- but larger batches of such rows are not).  One row less and it fits.  The grid (= number of partial filters = workspace size) does not depend on the tile height.
 static void wgrad_tile_for_linear_walk(const srx_conv_desc* d, Plan* p) {
     if (p->NTX != 1 || !knobs().wgrad_lin) return;
     const size_t slot_bytes = (size_t)((p->cinp == 4) ? 4 : p->cinp + 4) * 4;

@@ -6,16 +6,23 @@ TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module, and only as the checker / the CPU figure.
 The product package (ml_super_resolution_amd) never imports it.
 
-PARITY STATUS: "parity unpinned" for conv / backward / optimizer arithmetic: the
-reference (imironhead/ml_super_resolution) delegates those to TensorFlow 1.8, which
-is absent from /root/reference and not installable here, and the reference holds no
-tests or golden vectors.  Pinned by reference data / code:
+PARITY STATUS: "parity unpinned" for backward / optimizer arithmetic: the reference
+(imironhead/ml_super_resolution) delegates the arithmetic to TensorFlow 1.8, which is
+absent from /root/reference and not installable here, and the reference holds no
+tests or golden vectors.  The FORWARD convolution is pinned by the
+reference's own feature maps since round 3 (P7).  Pinned by reference data / code:
   P1  the sub-pixel index map: three independent reference spellings restated
       verbatim-in-behaviour below (`*_ref_spelling_*`) must agree with the closed
       form used everywhere else;
   P2  conv.N taps are post-ReLU (assets vdsr-fig2-conv.N == vdsr-fig2-relu.N);
   P3  residual add + truncating uint8 encode (assets vdsr-fig2-{sd,conv.20,sr});
-  P4  SRCNN VALID geometry 243 -> 231.
+  P4  SRCNN VALID geometry 243 -> 231;
+  P5  scipy.misc.imresize == Pillow's integer resample: assets/enet_eagle_bq.png, 0 differing bytes;
+  P6  tf.image.resize_bicubic (TF 1.x) reproduces the reference's SRCNN hd | sd panels to JPEG noise;
+  P7  conv2d_fwd = 3x3 support + bias + ReLU clamp + zero SAME padding (+ residual add): weights fitted
+      from assets/vdsr-fig2-conv.N.png off four held-out corners predict those corners, image border
+      included, to the encoding's quantisation noise; edge / reflect padding miss the border 2-20x
+      (tests/golden/make_pin_p7.py, tests/test_oracle_pins.py::test_p7_*).
 All citations are relative to /root/reference.
 """
 import ctypes

@@ -31,9 +31,15 @@ def test_descriptor_validation_without_gpu():
     ws = L.srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_BWD_FILTER)
     assert ws > 0 and ws % 4 == 0
     assert L.srx_conv2d_workspace_bytes(ctypes.byref(d), _lib.OP_FWD) == 256     # optional tile counter
-    bad = _lib.ConvDesc(256, 41, 41, 64, 64, 3, 3, 2, 0, 1, 0, 0)          # stride 2
+    s2 = _lib.ConvDesc(256, 41, 41, 64, 64, 3, 3, 2, 0, 1, 0, 0)           # stride 2: forward and filter gradient (round 3)
+    ws2 = L.srx_conv2d_workspace_bytes(ctypes.byref(s2), _lib.OP_BWD_FILTER)
+    assert ws2 > 0 and ws2 % 4 == 0
+    bad = _lib.ConvDesc(256, 41, 41, 64, 64, 3, 3, 3, 0, 1, 0, 0)          # stride 3
     assert L.srx_conv2d_workspace_bytes(ctypes.byref(bad), _lib.OP_BWD_FILTER) == 0
     assert b'stride' in L.srx_last_error()
+    # the data gradient of a stride-2 layer is a composition (zero stuffing + stride-1 data gradient): refused, by name
+    rc = L.srx_conv2d_bwd_data(ctypes.byref(s2), None, None, None, 0, None, None, 0, None)
+    assert rc == -1 or b'bwd_data at stride 2' in L.srx_last_error()
     # null pointers are rejected before any launch
     rc = L.srx_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None)
     assert rc == -1 and b'null' in L.srx_last_error()
