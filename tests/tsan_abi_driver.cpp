@@ -23,7 +23,8 @@ bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t
 hipError_t launch_reduce_partials(const float*, int, int, int, int, float*, float*, const float*, float, hipStream_t) { return hipSuccess; }
 hipError_t launch_reduce_partials_pairs(const float*, int, int, int, int, float*, float*, int, int, hipStream_t) { return hipSuccess; }
 bool launch_wgrad_lin_pairs(const ConvKey&, const WgradPairs&, int, int, size_t, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
-hipError_t launch_subpixel(const float*, float*, int, int, int, int, int, bool, hipStream_t) { return hipSuccess; }
+hipError_t launch_subpixel(const float*, float*, int, int, int, int, int, bool, const SubpixelTune&, hipStream_t) { return hipSuccess; }
+hipError_t launch_stream_copy(const float*, float*, size_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_mse(const float*, const float*, size_t, float, float*, int, float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_l2(const float*, const float*, size_t, float, float*, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_adam(float*, const float*, float*, float*, size_t, float, float, float, float, float, hipStream_t) { return hipSuccess; }
@@ -55,11 +56,11 @@ static void worker(int id) {
         const size_t b = srx_conv2d_workspace_bytes(&d, SRX_OP_BWD_FILTER);
         if (a == 0 || a != b) failures++;
         if ((it & 15) == 0) srx_set_conv_path(it & 16 ? 1 : 0);
-        // an argument error: the text is thread-local and names THIS thread's stride
-        d.stride = 2 + id;
+        // an argument error: the text is thread-local and names THIS thread's stride (1 and 2 are implemented)
+        d.stride = 3 + id;
         if (srx_conv2d_fwd(&d, buf[id], buf[id], nullptr, nullptr, buf[id], nullptr, 0, nullptr) != SRX_ERR_UNSUPPORTED) failures++;
         char want[32];
-        snprintf(want, sizeof(want), "stride %d:", 2 + id);
+        snprintf(want, sizeof(want), "stride %d:", 3 + id);
         if (!strstr(srx_last_error(), want)) failures++;
         // a planned (stubbed) launch
         d.stride = 1;
