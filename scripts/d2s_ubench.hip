@@ -106,11 +106,11 @@ __global__ __launch_bounds__(256) void chunked(const float* __restrict__ in, flo
 }
 
 // every chunk of the workgroup (at most DEPTH) requested before the first one is touched; MODE as in `chunked`
-template <int KMAX, int DEPTH, int MODE>
+template <int KMAX, int DEPTH, int MODE, bool CONTIG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void upfront(const float* __restrict__ in, float* __restrict__ out, int nfull, int chunk_floats, const int* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int c = blockIdx.x, G = gridDim.x;
+    const int c = CONTIG ? blockIdx.x * DEPTH : blockIdx.x, G = CONTIG ? 1 : gridDim.x;   // CONTIG: the workgroup's chunks are neighbours
     if (c >= nfull) return;
     const int c4 = chunk_floats >> 2;
     const unsigned chunk_bytes = (unsigned)chunk_floats * 4u;
@@ -224,6 +224,20 @@ int main() {
         timeit("Ea E with line-aligned chunks (one chunk per workgroup)", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(na), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
         timeit("Ua U0 with line-aligned chunks (all up front, no LDS)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
         timeit("Ua1 U1 with line-aligned chunks (all up front, LDS identity)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 1>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca, dtab); });
+    }
+    {
+        const int ca = 4608, na = (int)(nfl / ca);
+        const size_t la = (size_t)ca * 8 + 4096;
+        timeit("Uc all up front, aligned chunks, CONTIGUOUS chunks per wg (841 wgs x 3), no LDS", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0, true>), dim3((na + 2) / 3), dim3(256), 0, 0, in[i], out[i], na, ca, dtab); });
+        timeit("Uc1 the same through LDS (identity gather)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 1, true>), dim3((na + 2) / 3), dim3(256), la, 0, in[i], out[i], na, ca, dtab); });
+        const int cf = 5120, nf = (int)(nfl / cf);     // full slots: 5 float4 per thread, nothing out of range
+        const size_t lf = (size_t)cf * 8 + 4096;
+        timeit("Uf all up front, chunks of 5120 floats (5 FULL slots), strided chunks, no LDS", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
+        timeit("Ufc the same, contiguous chunks per wg (757 wgs x 3)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 0, true>), dim3((nf + 2) / 3), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
+        timeit("Ufc1 the same through LDS (identity gather)", [&](int i) { hipLaunchKernelGGL((upfront<5, 3, 1, true>), dim3((nf + 2) / 3), dim3(256), lf, 0, in[i], out[i], nf, cf, dtab); });
+        timeit("Bf  depth-1 chunked, chunks of 5120 floats, 1024 wgs, no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
+        timeit("Ef  one chunk of 5120 floats per wg, no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(nf), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
+        timeit("Ef1 one chunk of 5120 floats per wg through LDS (22 KB: 7 per CU)", [&](int i) { hipLaunchKernelGGL((chunked<5, 1>), dim3(nf), dim3(256), (size_t)cf * 4 + 4096 + 100, 0, in[i], out[i], nf, cf, dtab); });
     }
     timeit("F  D with 2624 wgs (one chunk each)", [&](int i) { hipLaunchKernelGGL((chunked<5, 2>), dim3(nfull), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
     return 0;
