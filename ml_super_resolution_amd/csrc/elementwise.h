@@ -6,8 +6,9 @@ namespace srx {
 constexpr int kReduceBlocks = 1024;  // partial slots a reduction may use (srx_reduce_scratch_bytes)
 
 // chunk_kb: a chunk grows while twice its size stays within this many KiB; db: two LDS buffers (software pipeline);
-// grid: cap of the persistent grid; depth: chunks of loads in flight per workgroup (0 = automatic)
-struct SubpixelTune { int chunk_kb, db, grid, depth; };
+// grid: cap of the persistent grid; depth: chunks of loads in flight per workgroup (0 = automatic);
+// throttle: requests a wave keeps in flight (0 = counted waits only)
+struct SubpixelTune { int chunk_kb, db, grid, depth, throttle; };
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
                            const SubpixelTune& tune, hipStream_t s);
 hipError_t launch_stream_copy(const float* in, float* out, size_t bytes, hipStream_t s);

@@ -220,7 +220,13 @@ __global__ __launch_bounds__(256) void subpixel_lds_kernel(const float* __restri
 // * The loads go out before the index computation, which then runs under the memory latency.
 // * The barrier is the raw s_barrier behind an LDS-only wait: __syncthreads() would also drain the vector-memory queue.
 // KMAX = ceil(chunk_floats / 4 / 256): only the last slot has lanes beyond the chunk.
-template <int KMAX, int DEPTH>
+// THR > 0: at most THR vector-memory requests of a wave in flight (s_waitcnt vmcnt(THR - 1) behind every load and store).
+// More is NOT better for a streaming kernel on this memory system (scripts/d2s_ubench.hip, profiles/r03_d2s_ubench.txt):
+// the fastest plain copy of this tensor keeps ONE request per wave in flight at 32 waves per CU (15.5 us); the same copy
+// with 6 per wave takes 17.3 us.  At this kernel's 16 waves per CU (a copy in its structure): 1 -> 19.1, 2 -> 17.0, 3 -> 16.6,
+// 4 -> 16.0, unbounded (the 5 loads of the next chunk + the 5 stores of this one) 16.9 us; the kernel itself: unbounded 17.5,
+// 2 -> 17.1, 3 -> 16.8, 4 -> 17.0, 5-8 -> 17.2 us.
+template <int KMAX, int DEPTH, int THR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))   // four workgroups per CU: <= 128 registers
 void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             int nfull, int chunk_floats, SubpixelGeom geo) {
@@ -236,15 +242,29 @@ void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)(ok ? chunk : 0) * chunk_floats), 0,
                                                  ok ? chunk_bytes : 0u, 0x00020000);
     };
+    auto throttle = [&]() {
+        if constexpr (THR == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (THR == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if constexpr (THR == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (THR == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (THR == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (THR == 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if constexpr (THR == 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (THR == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    };
     u32x4v v[DEPTH][KMAX];
-    auto issue = [&](u32x4v (&dst)[KMAX], int chunk) {
+    // (the first chunk's loads are not throttled: the wave goes on to its index arithmetic, not to more requests)
+    auto issue = [&](u32x4v (&dst)[KMAX], int chunk, bool throttled) {
         const __amdgpu_buffer_rsrc_t rs = rsrc_at(in, chunk);
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2 /* nt */);
+        for (int k = 0; k < KMAX; ++k) {
+            dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2 /* nt */);
+            if (throttled) throttle();
+        }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        issue(v[d], c + d * G);
+        issue(v[d], c + d * G, false);
         const __amdgpu_buffer_rsrc_t rs = rsrc_at(out, nfull);   // empty: the stores are dropped
         const u32x4v z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -284,7 +304,7 @@ void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
 #pragma unroll
         for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = reg[k];
         reinterpret_cast<u32x4v*>(lds)[last_in ? p * c4 + last_i : 2 * c4 + threadIdx.x] = reg[KMAX - 1];
-        issue(reg, cur + DEPTH * G);
+        issue(reg, cur + DEPTH * G, true);
         lds_barrier();
         const __amdgpu_buffer_rsrc_t ro = rsrc_at(out, cur);
         const char* bytes = reinterpret_cast<const char*>(buf);
@@ -303,6 +323,7 @@ void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
             for (int k = k0; k < k0 + GB && k < KMAX; ++k) {
                 const f32x4 o = unrotate4(g[k - k0][0], g[k - k0][1], g[k - k0][2], g[k - k0][3], r1, r2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, store_off + k * 4096, 0, 2);
+                throttle();
             }
         }
     };
@@ -405,16 +426,28 @@ __global__ __launch_bounds__(256) void subpixel_direct_kernel(const float* __res
 
 // DEPTH * KMAX float4s of data per thread must fit beside the gather offsets in 128 registers (four workgroups per
 // CU): the instances that would spill are not built (K = 6, 7 at depth 2; K >= 6 at depth 3).
+template <int K, int THR>
+static void launch_subpixel_pipe_t(int depth, int grid, size_t lds, hipStream_t s, const float* in, float* out, int nfull, int chunk,
+                                   const SubpixelGeom& geo) {
+    if constexpr (K <= 5 && THR == 0) {     // (the deeper variants exist for the A/B record of DESIGN 3.3 only)
+        if (depth >= 3) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 3, 0>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
+        if (depth >= 2) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 2, 0>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
+    }
+    hipLaunchKernelGGL((subpixel_pipe_kernel<K, 1, THR>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo);
+}
+// DEPTH * KMAX float4s of data per thread must fit beside the gather offsets in 128 registers (four workgroups per CU).
 template <int K>
-static void launch_subpixel_pipe(int depth, int grid, size_t lds, hipStream_t s, const float* in, float* out, int nfull, int chunk,
+static void launch_subpixel_pipe(int depth, int thr, int grid, size_t lds, hipStream_t s, const float* in, float* out, int nfull, int chunk,
                                  const SubpixelGeom& geo) {
-    if constexpr (K <= 5) {
-        if (depth >= 3) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 3>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
+    switch (thr) {
+        case 0: launch_subpixel_pipe_t<K, 0>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        case 2: launch_subpixel_pipe_t<K, 2>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        case 4: launch_subpixel_pipe_t<K, 4>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        case 5: launch_subpixel_pipe_t<K, 5>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        case 6: launch_subpixel_pipe_t<K, 6>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        case 8: launch_subpixel_pipe_t<K, 8>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
+        default: launch_subpixel_pipe_t<K, 3>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
     }
-    if constexpr (K <= 5 || K == 8) {
-        if (depth >= 2) { hipLaunchKernelGGL((subpixel_pipe_kernel<K, 2>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo); return; }
-    }
-    hipLaunchKernelGGL((subpixel_pipe_kernel<K, 1>), dim3(grid), dim3(256), lds, s, in, out, nfull, chunk, geo);
 }
 
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
@@ -454,7 +487,7 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
         } else if (nfull) {
             int grid = (int)(nfull < cap ? nfull : cap);
             if ((size_t)grid < nfull) grid -= grid % 8;   // every chunk of a workgroup starts at the same offset into a 128-byte line
-#define SRX_SUBPIXEL_PIPE(K) case K: launch_subpixel_pipe<K>(depth, grid, pipe_lds, s, in, out, (int)nfull, chunk, geo); break;
+#define SRX_SUBPIXEL_PIPE(K) case K: launch_subpixel_pipe<K>(depth, kn.throttle, grid, pipe_lds, s, in, out, (int)nfull, chunk, geo); break;
             // chunks of loads in flight per workgroup
             const int per_wg = (int)((nfull + grid - 1) / grid);
             const int depth = kn.depth > 0 ? (kn.depth < per_wg ? kn.depth : per_wg) : 1;   // (measured: deeper is slower)

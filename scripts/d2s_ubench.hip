@@ -162,6 +162,124 @@ void upfront(const float* __restrict__ in, float* __restrict__ out, int nfull, i
     }
 }
 
+// copy_a with bounds-checked buffer operations instead of global ones (one resource over the whole tensor)
+template <int KMAX, int FLAGS>
+__global__ __launch_bounds__(256) void copy_buf(const float* __restrict__ in, float* __restrict__ out, unsigned bytes) {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, bytes, FLAGS);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, FLAGS);
+    const unsigned per = KMAX * 4096u;
+    for (unsigned base = blockIdx.x * per; base < bytes; base += gridDim.x * per) {
+        u32x4v v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(ri, base + k * 4096 + threadIdx.x * 16, 0, 2);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) __builtin_amdgcn_raw_buffer_store_b128(v[k], ro, base + k * 4096 + threadIdx.x * 16, 0, 2);
+    }
+}
+
+// which side pays for buffer operations?  MODE 1: buffer loads + global stores; 2: global loads + buffer stores
+template <int KMAX, int MODE>
+__global__ __launch_bounds__(256) void copy_mix(const float* __restrict__ in, float* __restrict__ out, unsigned bytes) {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+    const unsigned per = KMAX * 4096u;
+    for (unsigned base = blockIdx.x * per; base < bytes; base += gridDim.x * per) {
+        u32x4v v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned off = base + k * 4096 + threadIdx.x * 16;
+            if (MODE == 1) v[k] = __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 2);
+            else v[k] = __builtin_bit_cast(u32x4v, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(in) + off)));
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned off = base + k * 4096 + threadIdx.x * 16;
+            if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(v[k], ro, off, 0, 2);
+            else __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v[k]), reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out) + off));
+        }
+    }
+}
+
+// How many requests per wave should be in flight?  copy_a (the fastest copy) turns out to be fully serialised by the
+// compiler (per-lane predicates -> s_waitcnt vmcnt(0) in front of EVERY load and store).  WAITS 1: the same explicitly
+// (one request per wave at a time); 2: all loads, wait, all stores, wait; 3: loads in flight two at a time, stores one
+// at a time; 0: counted waits (store k as soon as load k has landed)
+template <int KMAX, int WAITS>
+__global__ __launch_bounds__(256) void copy_thr(const float* __restrict__ in, float* __restrict__ out, unsigned bytes) {
+    const unsigned per = KMAX * 4096u;
+    for (unsigned base = blockIdx.x * per; base < bytes; base += gridDim.x * per) {
+        f32x4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned off = base + k * 4096 + threadIdx.x * 16;
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(in) + off));
+            if (WAITS == 1 || (WAITS == 3 && (k & 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (WAITS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned off = base + k * 4096 + threadIdx.x * 16;
+            __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out) + off));
+            if (WAITS == 1 || WAITS == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (WAITS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// the map's structure (persistent workgroups, 4 per CU, chunks of `chunk_floats`, next chunk's loads issued before the
+// current chunk's stores) with the number of requests a wave keeps in flight capped at THR (0 = counted waits only)
+template <int KMAX, int THR, bool LDS>
+__global__ __launch_bounds__(256) void chunked_thr(const float* __restrict__ in, float* __restrict__ out, int nfull, int chunk_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int c = blockIdx.x;
+    if (c >= nfull) return;
+    const int G = gridDim.x;
+    const int c4 = chunk_floats >> 2;
+    auto throttle = [&]() {
+        if (THR == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (THR == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (THR == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (THR == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+    f32x4 v[KMAX];
+    int idx[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { const int i = k * 256 + threadIdx.x; idx[k] = i < c4 ? i : c4 - 1; }   // clamped: duplicates, no predicate
+    auto issue = [&](int chunk) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + (size_t)chunk * c4;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { v[k] = __builtin_nontemporal_load(src + idx[k]); throttle(); }
+    };
+    issue(c);
+    int p = 0;
+    for (; c < nfull; c += G, p ^= 1) {
+        f32x4 w[KMAX];
+        if (LDS) {
+            f32x4* buf4 = reinterpret_cast<f32x4*>(lds + p * chunk_floats);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) buf4[idx[k]] = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) w[k] = v[k];
+        }
+        if (c + G < nfull) issue(c + G);
+        if (LDS) {
+            lds_barrier();
+            const float* buf = lds + p * chunk_floats;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[k][e] = buf[4 * idx[k] + e];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(out) + (size_t)c * c4;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k * 256 + (int)threadIdx.x < c4) __builtin_nontemporal_store(w[k], dst + idx[k]);
+            throttle();
+        }
+    }
+}
+
 int main() {
     const int P = 8;
     const size_t nfl = (size_t)256 * 41 * 41 * 27;
@@ -238,6 +356,47 @@ int main() {
         timeit("Bf  depth-1 chunked, chunks of 5120 floats, 1024 wgs, no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(1024), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
         timeit("Ef  one chunk of 5120 floats per wg, no LDS", [&](int i) { hipLaunchKernelGGL((chunked<5, 0>), dim3(nf), dim3(256), 0, 0, in[i], out[i], nf, cf, dtab); });
         timeit("Ef1 one chunk of 5120 floats per wg through LDS (22 KB: 7 per CU)", [&](int i) { hipLaunchKernelGGL((chunked<5, 1>), dim3(nf), dim3(256), (size_t)cf * 4 + 4096 + 100, 0, in[i], out[i], nf, cf, dtab); });
+    }
+    {   // half-size chunks, twice the workgroups: every load of the tensor in flight at once AND few loads per thread
+        const int ch = 2304, nh = (int)(nfl / ch);      // 2304 floats = 72 lines; 2.25 slots -> KMAX 3
+        const size_t lh = (size_t)ch * 8 + 4096;
+        timeit("H0 chunks of 2304 floats, 2048 wgs, 3 chunks up front (<= 9 float4/thread), no LDS", [&](int i) { hipLaunchKernelGGL((upfront<3, 3, 0>), dim3(2048), dim3(256), 0, 0, in[i], out[i], nh, ch, dtab); });
+        timeit("H1 the same through LDS (identity gather), 8 wgs per CU", [&](int i) { hipLaunchKernelGGL((upfront<3, 3, 1>), dim3(2048), dim3(256), lh, 0, in[i], out[i], nh, ch, dtab); });
+        timeit("H0c contiguous chunks per wg (1682 wgs x 3), no LDS", [&](int i) { hipLaunchKernelGGL((upfront<3, 3, 0, true>), dim3((nh + 2) / 3), dim3(256), 0, 0, in[i], out[i], nh, ch, dtab); });
+        timeit("H1c the same through LDS", [&](int i) { hipLaunchKernelGGL((upfront<3, 3, 1, true>), dim3((nh + 2) / 3), dim3(256), lh, 0, in[i], out[i], nh, ch, dtab); });
+        const int cq = 2048, nq = (int)(nfl / cq);      // 2 full slots
+        const size_t lq = (size_t)cq * 8 + 4096;
+        timeit("Q0 chunks of 2048 floats (2 full slots), 1892 wgs x 3 contiguous, no LDS", [&](int i) { hipLaunchKernelGGL((upfront<2, 3, 0, true>), dim3((nq + 2) / 3), dim3(256), 0, 0, in[i], out[i], nq, cq, dtab); });
+        timeit("Q1 the same through LDS", [&](int i) { hipLaunchKernelGGL((upfront<2, 3, 1, true>), dim3((nq + 2) / 3), dim3(256), lq, 0, in[i], out[i], nq, cq, dtab); });
+        timeit("Q0s chunks of 2048 floats, 2048 wgs strided x 3, no LDS", [&](int i) { hipLaunchKernelGGL((upfront<2, 3, 0>), dim3(2048), dim3(256), 0, 0, in[i], out[i], nq, cq, dtab); });
+        timeit("Q1s the same through LDS", [&](int i) { hipLaunchKernelGGL((upfront<2, 3, 1>), dim3(2048), dim3(256), lq, 0, in[i], out[i], nq, cq, dtab); });
+    }
+    timeit("G1 copy A3 (6 float4/thread, 1892 wgs) with BUFFER loads / stores, resource word 3 = 0x00020000", [&](int i) { hipLaunchKernelGGL((copy_buf<6, 0x00020000>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("G2 the same, resource word 3 = 0x00027000 (dst_sel xyzw)", [&](int i) { hipLaunchKernelGGL((copy_buf<6, 0x00027000>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("G3 copy A (8 float4/thread, 2048 wgs) with buffer operations", [&](int i) { hipLaunchKernelGGL((copy_buf<8, 0x00020000>), dim3(2048), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("G4 copy A3 with buffer LOADS + global stores", [&](int i) { hipLaunchKernelGGL((copy_mix<6, 1>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("G5 copy A3 with global loads + buffer STORES", [&](int i) { hipLaunchKernelGGL((copy_mix<6, 2>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T0 copy 6 float4/thread, 1892 wgs, global ops, counted waits", [&](int i) { hipLaunchKernelGGL((copy_thr<6, 0>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T1 the same, ONE request per wave at a time (vmcnt(0) after every load and store)", [&](int i) { hipLaunchKernelGGL((copy_thr<6, 1>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T2 the same, all loads - wait - all stores - wait", [&](int i) { hipLaunchKernelGGL((copy_thr<6, 2>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T3 the same, loads two at a time, stores one at a time", [&](int i) { hipLaunchKernelGGL((copy_thr<6, 3>), dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T1' one request per wave at a time, 5 float4/thread, 1024 wgs (the map's occupancy: 4 wgs per CU by LDS)", [&](int i) { hipLaunchKernelGGL((copy_thr<5, 1>), dim3(1024), dim3(256), 40000, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T2' all loads - wait - all stores - wait, 5 float4/thread, 1024 wgs, 4 per CU", [&](int i) { hipLaunchKernelGGL((copy_thr<5, 2>), dim3(1024), dim3(256), 40000, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T0' counted waits, 5 float4/thread, 1024 wgs, 4 per CU", [&](int i) { hipLaunchKernelGGL((copy_thr<5, 0>), dim3(1024), dim3(256), 40000, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T1'' one request at a time, 5 float4/thread, 2270 wgs (one iteration each), 7 per CU (22 KB LDS)", [&](int i) { hipLaunchKernelGGL((copy_thr<5, 1>), dim3(2270), dim3(256), 22000, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    timeit("T2'' all loads - wait - all stores, 5 float4/thread, 2270 wgs, 7 per CU", [&](int i) { hipLaunchKernelGGL((copy_thr<5, 2>), dim3(2270), dim3(256), 22000, 0, in[i], out[i], (unsigned)(nfl * 4)); });
+    {
+        const int ca = 4608, na = (int)(nfl / ca);
+        const size_t la = (size_t)ca * 8 + 4096;
+        timeit("V0 map structure (aligned chunks, 1024 wgs, 4 per CU), global ops, no LDS, counted waits", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 0, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("V1 ... at most 1 request per wave in flight", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 1, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("V2 ... at most 2", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 2, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("V3 ... at most 3", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 3, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("V4 ... at most 4", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 4, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("W0 the same through LDS (identity gather), counted waits", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 0, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("W2 through LDS, at most 2 in flight", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 2, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("W3 through LDS, at most 3 in flight", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 3, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
+        timeit("W4 through LDS, at most 4 in flight", [&](int i) { hipLaunchKernelGGL((chunked_thr<5, 4, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca); });
     }
     timeit("F  D with 2624 wgs (one chunk each)", [&](int i) { hipLaunchKernelGGL((chunked<5, 2>), dim3(nfull), dim3(256), lds2, 0, in[i], out[i], nfull, chunk, dtab); });
     return 0;

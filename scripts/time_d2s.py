@@ -11,7 +11,8 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SWEEP = [{}, {'SRX_SUBPIXEL_DB': '2'}, {'SRX_SUBPIXEL_DB': '0'}, {'SRX_SUBPIXEL_GRID': '768'}, {'SRX_SUBPIXEL_GRID': '1280'}]
+SWEEP = [{}, {'SRX_SUBPIXEL_THROTTLE': '0'}, {'SRX_SUBPIXEL_THROTTLE': '2'}, {'SRX_SUBPIXEL_THROTTLE': '3'}, {'SRX_SUBPIXEL_THROTTLE': '5'},
+         {'SRX_SUBPIXEL_THROTTLE': '6'}, {'SRX_SUBPIXEL_THROTTLE': '8'}]
 
 
 def one():
