@@ -508,8 +508,9 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
             const int grid = (int)(tchunks < cap ? tchunks : cap);
 #define SRX_SUBPIXEL_LAUNCH(K)                                                                                   \
             hipLaunchKernelGGL((subpixel_lds_kernel<K>), dim3(grid), dim3(256), chunk * 4, s, tin, tout, ttotal, chunk, geo);
-            if (kneed <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
-            else if (kneed <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
+            const int kplain = (chunk / 4 + 255) / 256;     // (no shift here: float4 slots of the chunk itself, <= 12 for 48 KiB)
+            if (kplain <= 4) { SRX_SUBPIXEL_LAUNCH(4) }
+            else if (kplain <= 8) { SRX_SUBPIXEL_LAUNCH(8) }
             else { SRX_SUBPIXEL_LAUNCH(12) }
 #undef SRX_SUBPIXEL_LAUNCH
         }

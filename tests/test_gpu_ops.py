@@ -204,7 +204,8 @@ def test_subpixel_random_shapes_every_kernel_route(ops):
     rng = np.random.default_rng(2024)
     shapes = [(int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 90)), int(rng.integers(1, 5)), int(rng.integers(1, 5)))
               for _ in range(60)]
-    shapes += [(2, 3, 1100, 3, 3), (1, 2, 4000, 3, 2), (1, 1, 700, 4, 4), (700, 41, 41, 3, 3), (3, 1500, 9, 1, 2), (1, 5, 333, 3, 4)]
+    shapes += [(2, 3, 1100, 3, 3), (1, 2, 4000, 3, 2), (1, 1, 700, 4, 4), (700, 41, 41, 3, 3), (3, 1500, 9, 1, 2), (1, 5, 333, 3, 4),
+               (1, 3, 1024, 3, 2), (2, 2, 1024, 1, 3)]      # one block = 48 KiB / 36 KiB: the single-buffer kernel's largest chunks
     for (n, h, w, c, r) in shapes:
         bits = rng.integers(0, 1 << 32, size=(n, h, w, c * r * r), dtype=np.uint64).astype(np.uint32)
         t = torch.from_numpy(bits.view(np.int32)).cuda().view(torch.float32)
