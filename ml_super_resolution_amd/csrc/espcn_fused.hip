@@ -5,8 +5,10 @@
 //
 // At that size the three layers are 0.57 GFLOP and three launches are three latency-bound ramps (9 + 14 + 9 us of
 // kernel time plus the gaps between dependent launches).  Here a workgroup owns a tile of <= 9x9 LR output pixels and
-// chains the layers through LDS: the 17x17 input halo, t1 on the tile grown by 2 (13x13 x 64 channels), t2 on the tile
-// grown by 1 (11x11 x 32), then the output straight through the sub-pixel map.  Positions of t1 / t2 outside the image
+// chains the layers through LDS: the input halo (tile grown by 4), t1 on the tile grown by 2 (<= 13x13 x 64 channels),
+// t2 on the tile grown by 1 (<= 11x11 x 32), then the output straight through the sub-pixel map.  The host cuts the
+// image into the tile shape that needs the fewest rounds of workgroups and the least MFMA work per tile ([32,17,17]:
+// 2 x 3 tiles of 9 x 6 = 192 workgroups; round 2 used 2 x 2 of 9 x 9 = 128: 29.5 -> 22.7 us).  Positions of t1 / t2 outside the image
 // are stored as zeros (SAME padding pads the LAYER INPUT).  Halo pixels are computed by every tile that needs them
 // (f1 x2.1, f2 x1.5 at 9x9 tiles): worth it only while the problem is latency-bound -- the host uses this kernel for
 // small problems and the three-launch path otherwise.  All three filter slices of a wave (25 + 144 + 72 registers) are
@@ -26,7 +28,7 @@ struct EspcnArgs {
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     float* hr;
     int N, H, W, r, C3;          // C3 = 3 r^2
-    int T;                       // tile edge (<= 9)
+    int TY, TX;                  // tile (<= 9 x 9 LR output pixels)
     int tiles_y, tiles_x, units;
 };
 
@@ -40,6 +42,145 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
     return v;
+}
+
+// A wave's sub-tiles of a phase are m = first, first + step, ... (count of them); they are processed in groups of G <= 4
+// accumulators, the groups evened out (9 sub-tiles: 3 + 3 + 3, not 4 + 4 + 1 with three idle accumulators' worth of
+// MFMAs): the group bodies below are templates on G, picked by a wave-uniform switch outside the tap loops.
+#define SRX_ESPCN_GROUPS(BODY)                                                                                 \
+    {                                                                                                          \
+        const int ng_ = (count + 3) >> 2;                                                                      \
+        const int base_ = ng_ ? count / ng_ : 0, rem_ = ng_ ? count % ng_ : 0;                                 \
+        int m_ = first;                                                                                        \
+        for (int gi_ = 0; gi_ < ng_; ++gi_) {                                                                  \
+            const int g_ = base_ + (gi_ < rem_ ? 1 : 0);                                                       \
+            switch (g_) {                                                                                      \
+                case 1: BODY(1) break;                                                                         \
+                case 2: BODY(2) break;                                                                         \
+                case 3: BODY(3) break;                                                                         \
+                default: BODY(4) break;                                                                        \
+            }                                                                                                  \
+            m_ += g_ * step;                                                                                   \
+        }                                                                                                      \
+    }
+
+// ---- f1: 5x5, 3 -> 64, tanh, on the tile grown by 2
+template <int G>
+__device__ __forceinline__ void espcn_f1_group(const EspcnArgs& a, const float* X0, float* T1, const float (&w1r)[25], f32x4 b1r,
+                                               int m0, int step, int n1, int w0, int w1, int oy, int ox, int wave, int li, int kq) {
+    int la[G];
+    f32x4 acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        const int tt = t < n1 ? t : 0;
+        const int r = tt / w1, c = tt - r * w1;
+        la[i] = (r * w0 + c) * 4 + kq;
+        acc[i] = b1r;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+            float b[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) b[i] = X0[la[i] + (kh * w0 + kw) * 4];
+#pragma unroll
+            for (int i = 0; i < G; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[kh * 5 + kw], b[i], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        if (t < n1) {
+            const int r = t / w1, c = t - r * w1;
+            const bool in_img = (unsigned)(oy - 2 + r) < (unsigned)a.H && (unsigned)(ox - 2 + c) < (unsigned)a.W;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(T1 + t * kP1 + 16 * wave + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+        }
+    }
+}
+
+// ---- f2: 3x3, 64 -> 32, tanh, on the tile grown by 1
+template <int G>
+__device__ __forceinline__ void espcn_f2_group(const EspcnArgs& a, const float* T1, float* T2, const float (&w2r)[144], f32x4 b2r,
+                                               int m0, int step, int n2, int w1, int w2, int oy, int ox, int ch2, int li, int kq) {
+    int la[G];
+    f32x4 acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        const int tt = t < n2 ? t : 0;
+        const int r = tt / w2, c = tt - r * w2;
+        la[i] = (r * w1 + c) * kP1 + 4 * kq;
+        acc[i] = b2r;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 b[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + ((tap / 3) * w1 + (tap % 3)) * kP1 + 16 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[tap * 16 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        if (t < n2) {
+            const int r = t / w2, c = t - r * w2;
+            const bool in_img = (unsigned)(oy - 1 + r) < (unsigned)a.H && (unsigned)(ox - 1 + c) < (unsigned)a.W;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(T2 + t * kP2 + 16 * ch2 + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+        }
+    }
+}
+
+// ---- f3: 3x3, 32 -> 3 r^2, stored through the sub-pixel map
+template <int G>
+__device__ __forceinline__ void espcn_f3_group(const EspcnArgs& a, const float* T2, float* hr_img, const float (&w3r)[72],
+                                               const float (&b3r)[4], const int (&eo)[4], int m0, int step, int n3, int tw, int w2,
+                                               int oy, int ox, int rc, int ch3, int li, int kq) {
+    int la[G];
+    f32x4 acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        const int tt = t < n3 ? t : 0;
+        const int r = tt / tw, c = tt - r * tw;
+        la[i] = (r * w2 + c) * kP2 + 4 * kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = b3r[e];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 b[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap / 3) * w2 + (tap % 3)) * kP2 + 16 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[tap * 8 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int t = 16 * (m0 + i * step) + li;
+        if (t < n3) {
+            const int r = t / tw, c = t - r * tw;
+            float* o = hr_img + ((size_t)(oy + r) * a.r * a.W + (ox + c)) * rc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (16 * ch3 + 4 * kq + e < a.C3) o[eo[e]] = acc[i][e];
+        }
+    }
 }
 
 template <int NCH3>
@@ -58,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
 #pragma unroll
     for (int t = 0; t < 25; ++t) w1r[t] = (kq < 3) ? a.w1[(t * 3 + kq) * 64 + 16 * wave + li] : 0.f;
     f32x4 b1r = *reinterpret_cast<const f32x4*>(a.b1 + 16 * wave + 4 * kq);
-    // f2: chunk = wave & 1 (16 of the 32 channels); the two waves of a chunk split the sub-tiles
+    // f2: chunk = wave & 1 (16 of the 32 channels); the two waves of a chunk take the even / the odd sub-tiles
     const int ch2 = wave & 1, half2 = wave >> 1;
     float w2r[144];
 #pragma unroll
@@ -66,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
 #pragma unroll
         for (int j = 0; j < 16; ++j) w2r[t * 16 + j] = a.w2[(t * 64 + 16 * (j / 4) + 4 * kq + (j % 4)) * 32 + 16 * ch2 + li];
     f32x4 b2r = *reinterpret_cast<const f32x4*>(a.b2 + 16 * ch2 + 4 * kq);
-    // f3: chunk = wave % NCH3 of ceil(3 r^2 / 16); waves of a chunk split the sub-tiles
+    // f3: chunk = wave % NCH3 of ceil(3 r^2 / 16); the W3 waves of a chunk take every W3-th sub-tile
     constexpr int W3 = 4 / NCH3;             // waves per chunk (NCH3 = 3: one each, the fourth wave idles in this phase)
     const int ch3 = wave % NCH3, part3 = wave / NCH3;
     const bool on3 = part3 < W3;
@@ -94,9 +235,9 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
     for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
         const int tx_i = u % a.tiles_x, t2_ = u / a.tiles_x;
         const int ty_i = t2_ % a.tiles_y, n = t2_ / a.tiles_y;
-        const int oy = ty_i * a.T, ox = tx_i * a.T;
-        const int th = (a.H - oy < a.T) ? (a.H - oy) : a.T;
-        const int tw = (a.W - ox < a.T) ? (a.W - ox) : a.T;
+        const int oy = ty_i * a.TY, ox = tx_i * a.TX;
+        const int th = (a.H - oy < a.TY) ? (a.H - oy) : a.TY;
+        const int tw = (a.W - ox < a.TX) ? (a.W - ox) : a.TX;
         const int w0 = tw + 8, w1 = tw + 4, w2 = tw + 2;            // region widths: input halo, t1, t2
         const int n0 = (th + 8) * w0, n1 = (th + 4) * w1, n2 = (th + 2) * w2, n3 = th * tw;
 
@@ -114,121 +255,28 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
         }
         __syncthreads();
 
-        // ---- f1: 5x5, 3 -> 64, tanh, on the tile grown by 2; wave = channel chunk, all sub-tiles
-        for (int s0 = 0; s0 * 16 < n1; s0 += 4) {
-            int la[4];
-            f32x4 acc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = 16 * (s0 + i) + li;
-                const int tt = t < n1 ? t : 0;
-                const int r = tt / w1, c = tt - r * w1;
-                la[i] = (r * w0 + c) * 4 + kq;
-                acc[i] = b1r;
-            }
-#pragma unroll
-            for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    float b[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) b[i] = X0[la[i] + (kh * w0 + kw) * 4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[kh * 5 + kw], b[i], acc[i], 0, 0, 0);
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = 16 * (s0 + i) + li;
-                if (t < n1) {
-                    const int r = t / w1, c = t - r * w1;
-                    const bool in_img = (unsigned)(oy - 2 + r) < (unsigned)a.H && (unsigned)(ox - 2 + c) < (unsigned)a.W;
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(T1 + t * kP1 + 16 * wave + 4 * kq) = in_img ? tanh4(acc[i]) : z;
-                }
-            }
+        {   // f1: wave = channel chunk, all sub-tiles
+            const int first = 0, step = 1, count = (n1 + 15) >> 4;
+#define SRX_F1(G) espcn_f1_group<G>(a, X0, T1, w1r, b1r, m_, step, n1, w0, w1, oy, ox, wave, li, kq);
+            SRX_ESPCN_GROUPS(SRX_F1)
+#undef SRX_F1
         }
         __syncthreads();
-
-        // ---- f2: 3x3, 64 -> 32, tanh, on the tile grown by 1; wave = (chunk, half of the sub-tiles)
-        for (int s0 = 4 * half2; s0 * 16 < n2; s0 += 8) {
-            int la[4];
-            f32x4 acc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = 16 * (s0 + i) + li;
-                const int tt = t < n2 ? t : 0;
-                const int r = tt / w2, c = tt - r * w2;
-                la[i] = (r * w1 + c) * kP1 + 4 * kq;
-                acc[i] = b2r;
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 b[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + ((tap / 3) * w1 + (tap % 3)) * kP1 + 16 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[tap * 16 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = 16 * (s0 + i) + li;
-                if (t < n2) {
-                    const int r = t / w2, c = t - r * w2;
-                    const bool in_img = (unsigned)(oy - 1 + r) < (unsigned)a.H && (unsigned)(ox - 1 + c) < (unsigned)a.W;
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(T2 + t * kP2 + 16 * ch2 + 4 * kq) = in_img ? tanh4(acc[i]) : z;
-                }
-            }
+        {   // f2: wave = (chunk, even / odd sub-tiles)
+            const int nsub = (n2 + 15) >> 4;
+            const int first = half2, step = 2, count = (nsub - half2 + 1) >> 1;
+#define SRX_F2(G) espcn_f2_group<G>(a, T1, T2, w2r, b2r, m_, step, n2, w1, w2, oy, ox, ch2, li, kq);
+            SRX_ESPCN_GROUPS(SRX_F2)
+#undef SRX_F2
         }
         __syncthreads();
-
-        // ---- f3: 3x3, 32 -> 3 r^2, stored through the sub-pixel map; wave = (chunk, share of the sub-tiles)
-        if (on3) {
+        if (on3) {   // f3: wave = (chunk, every W3-th sub-tile)
             float* hr_img = a.hr + (size_t)n * a.H * a.r * hr_row;
-            for (int s0 = 4 * part3; s0 * 16 < n3; s0 += 4 * W3) {
-                int la[4];
-                f32x4 acc[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int t = 16 * (s0 + i) + li;
-                    const int tt = t < n3 ? t : 0;
-                    const int r = tt / tw, c = tt - r * tw;
-                    la[i] = (r * w2 + c) * kP2 + 4 * kq;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][e] = b3r[e];
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        f32x4 b[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap / 3) * w2 + (tap % 3)) * kP2 + 16 * g);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[tap * 8 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int t = 16 * (s0 + i) + li;
-                    if (t < n3) {
-                        const int r = t / tw, c = t - r * tw;
-                        float* o = hr_img + ((size_t)(oy + r) * a.r * a.W + (ox + c)) * rc;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (16 * ch3 + 4 * kq + e < a.C3) o[eo[e]] = acc[i][e];
-                    }
-                }
-            }
+            const int nsub = (n3 + 15) >> 4;
+            const int first = part3, step = W3, count = (nsub - part3 + W3 - 1) / W3;
+#define SRX_F3(G) espcn_f3_group<G>(a, T2, hr_img, w3r, b3r, eo, m_, step, n3, tw, w2, oy, ox, rc, ch3, li, kq);
+            SRX_ESPCN_GROUPS(SRX_F3)
+#undef SRX_F3
         }
     }
 }
@@ -249,23 +297,32 @@ extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b
     EspcnArgs a;
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.hr = hr;
     a.N = N; a.H = H; a.W = W; a.r = r; a.C3 = 3 * r * r;
-    // tile edge: the largest that fits, evened out over the image (17 -> 9 + 8, not 9 + 8 by luck: ceil(17 / 2))
-    const int ny = (H + kT - 1) / kT, nx = (W + kT - 1) / kT;
-    int T = (H + ny - 1) / ny;
-    const int Tx = (W + nx - 1) / nx;
-    if (Tx > T) T = Tx;
-    a.T = T;
-    a.tiles_y = (H + T - 1) / T; a.tiles_x = (W + T - 1) / T;
-    const long units = (long)N * a.tiles_y * a.tiles_x;
-    if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: too many tiles");
-    a.units = (int)units;
+    // Tile shape: <= 9 x 9, the image cut evenly in each direction; among the cuts that need the fewest rounds of
+    // workgroups over the CUs, the one with the least MFMA work per tile (every phase costs a tile its sub-tiles of 16
+    // pixels: 25 / 144 / 72 MFMAs each, shared by 4 / 2 / W3 waves).  [32,17,17]: 2 x 3 tiles of 9 x 6 = 192 workgroups in
+    // one round instead of 2 x 2 of 9 x 9 = 128.
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0 || cus > 256) cus = 256;
+    const int nch3 = (a.C3 + 15) / 16, waves3 = nch3 == 3 ? 1 : 4 / nch3;
+    long best_rounds = -1, best_cost = 0;
+    a.TY = a.TX = kT;
+    for (int ny = (H + kT - 1) / kT; ny <= H && ny <= (H + kT - 1) / kT + 2; ++ny)
+        for (int nx = (W + kT - 1) / kT; nx <= W && nx <= (W + kT - 1) / kT + 2; ++nx) {
+            const int ty = (H + ny - 1) / ny, tx = (W + nx - 1) / nx;
+            const long tiles = (long)N * ((H + ty - 1) / ty) * ((W + tx - 1) / tx);
+            const long rounds = (tiles + cus - 1) / cus;
+            const long s1 = ((ty + 4) * (tx + 4) + 15) / 16, s2 = ((ty + 2) * (tx + 2) + 15) / 16, s3 = (ty * tx + 15) / 16;
+            const long cost = rounds * (25 * s1 + 144 * ((s2 + 1) / 2) + 72 * ((s3 + waves3 - 1) / waves3) + 150);   // (+150: staging, barriers)
+            if (best_rounds < 0 || cost < best_cost) { best_rounds = rounds; best_cost = cost; a.TY = ty; a.TX = tx; }
+        }
+    a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_x = (W + a.TX - 1) / a.TX;
+    const long units = (long)N * a.tiles_y * a.tiles_x;
+    if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: too many tiles");
+    a.units = (int)units;
     const int grid = (int)(units < (long)cus ? units : (long)cus);
     const size_t lds = (size_t)(kX0 + kT1 + kT2) * 4;
     hipError_t e;
-    const int nch3 = (a.C3 + 15) / 16;
     if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1>, a, grid, lds, (hipStream_t)stream);
     else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2>, a, grid, lds, (hipStream_t)stream);
     else e = launch_with_lds(espcn_fused_kernel<3>, a, grid, lds, (hipStream_t)stream);
