@@ -21,6 +21,7 @@ tests/test_oracle_pins.py::test_p7_* (CPU, oracle) and tests/test_gpu_pins.py (H
 the held-out corners, borders included, from the previous layer's crop: decode -> conv2d SAME + bias + ReLU -> encode.
 
 Run:  python tests/golden/make_pin_p7.py            (about 15 minutes on 8 cores: 64 x 19 least-squares problems of ~50,000 x 577)
+      python tests/golden/make_pin_p7.py full20     (seconds: the whole image for the input and the output layer, pin_p7_layer{1,20}_full.npz)
 """
 import os
 import sys
@@ -117,5 +118,21 @@ def main():
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
 
 
+def full_layer20():
+    """The whole 256 x 256 image for the output layer: the reference's conv.19 maps, sd, conv.20 and sr as uint8 ->
+    pin_p7_layer20_full.npz (1.7 MB).  Used with the (w20, b20) of the fit above: every border pixel of the image (1,020
+    of them) was never part of that fit, nor were the four corner regions."""
+    maps, sr = load()
+    dst = os.path.join(os.path.dirname(OUT), 'pin_p7_layer20_full.npz')
+    np.savez_compressed(dst, conv19=maps[19], sd=maps[0], conv20=maps[NL], sr=sr)
+    print('wrote', dst, os.path.getsize(dst), 'bytes')
+    # ... and for the input layer (3 -> 64): the reference's conv.1 maps of the whole image (sd is in the file above)
+    dst = os.path.join(os.path.dirname(OUT), 'pin_p7_layer1_full.npz')
+    np.savez_compressed(dst, conv1=maps[1])
+    print('wrote', dst, os.path.getsize(dst), 'bytes')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full20':
+        sys.exit(full_layer20())
     sys.exit(main())

@@ -54,3 +54,31 @@ def test_p7_output_layer_residual_add_on_the_gpu(ops, conv_path):
     valid, _ = p7_masks(int(z['corner']))
     d = np.abs(enc - z['sr'].astype(np.int64))[valid]
     assert (d <= 1).mean() >= 0.99 and d.max() <= 2, ((d <= 1).mean(), d.max())
+
+
+def test_p7_the_whole_sr_image_on_the_gpu(ops, conv_path):
+    """The reference's ENTIRE sr_image.png from its conv.19.png through the C ABI: srx_conv2d_fwd (3x3 64 -> 3 with the
+    residual operand: conv_narrow_kernel, or the MFMA kernel on the other path) + srx_saturate_u8, 256 x 256, all four
+    image borders (every border pixel out of sample)."""
+    from tests.test_oracle_pins import p7_full20
+    z, f, ring = p7_full20()
+    x, sd = dev(p7_decode(f['conv19'])[None]), dev(p7_decode(f['sd'])[None])
+    sr = ops.conv2d_fwd(x, dev(z['w20']), dev(z['b20']), 'SAME', None, skip=sd)
+    d = np.abs(ops.saturate_u8(sr)[0].cpu().numpy().astype(np.int64) - f['sr'].astype(np.int64))
+    assert (d <= 1).mean() >= 0.999 and (d <= 1)[ring].mean() >= 0.995 and d.max() <= 2, ((d <= 1).mean(), (d <= 1)[ring].mean(), d.max())
+    res = ops.conv2d_fwd(x, dev(z['w20']), dev(z['b20']), 'SAME', None)
+    d20 = np.abs(ops.saturate_u8(res)[0].cpu().numpy().astype(np.int64) - f['conv20'].astype(np.int64))
+    assert (d20 <= 1).mean() >= 0.999 and (d20 <= 1)[ring].mean() >= 0.995 and d20.max() <= 2
+
+
+def test_p7_the_whole_conv1_image_on_the_gpu(ops, conv_path):
+    """The reference's ENTIRE conv.1.png (64 maps of 256 x 256) from its sd_image.png through srx_conv2d_fwd (3x3 3 -> 64 +
+    bias + ReLU, the RGB-input kernel) + srx_saturate_u8: every byte within one level, >= 97 % exact."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.test_oracle_pins import p7_full20
+    z, f, ring = p7_full20()
+    conv1 = np.load(os.path.join(GOLDEN, 'pin_p7_layer1_full.npz'))['conv1'].astype(np.int64)
+    y = ops.conv2d_fwd(dev(p7_decode(f['sd'])[None]), dev(z['w1']), dev(z['b1']), 'SAME', 'relu')
+    d = np.abs(ops.saturate_u8(y)[0].cpu().numpy().astype(np.int64) - conv1)
+    assert d.max() <= 1 and (d == 0).mean() >= 0.97, (d.max(), (d == 0).mean())

@@ -301,3 +301,46 @@ def test_p7_every_layer_interior():
             continue
         inner, _ = p7_errors(z, n, p7_predict(z, n, O.conv2d_fwd))
         assert inner <= 1.0, (n, inner)
+
+
+def p7_full20():
+    z, f = p7_load(), np.load(os.path.join(GOLDEN, 'pin_p7_layer20_full.npz'))
+    ring = np.zeros((256, 256), bool)
+    ring[0] = ring[-1] = True
+    ring[:, 0] = ring[:, -1] = True
+    return z, f, ring
+
+
+def test_p7_the_whole_sr_image_from_the_reference_conv19_maps():
+    """model_vdsr.py:85-106 end to end on the reference's own tensors: the reference's ENTIRE 256 x 256 sr_image.png is
+    reproduced from its conv.19.png (64 maps), its sd_image.png and the fitted output layer: sr = sd + conv3x3(relu.19) + b,
+    encoded.  Every one of the 1,020 border pixels of the image is out of sample (the fit used interior pixels only).
+    Zero SAME padding: >= 99.9 % of all bytes and >= 99.5 % of the border bytes within one level, none further than 2;
+    edge / reflect padding: barely half of the border bytes."""
+    z, f, ring = p7_full20()
+    x, sd = p7_decode(f['conv19'])[None], p7_decode(f['sd'])[None]
+    w, b = z['w20'].astype(np.float64), z['b20'].astype(np.float64)
+    res = O.conv2d_fwd(x, w, b, 'SAME', None)
+    d20 = np.abs(O.saturate_u8(res)[0].astype(np.int64) - f['conv20'].astype(np.int64))
+    dsr = np.abs(O.saturate_u8(sd + res)[0].astype(np.int64) - f['sr'].astype(np.int64))
+    for d in (d20, dsr):
+        assert (d <= 1).mean() >= 0.999 and (d <= 1)[ring].mean() >= 0.995 and d.max() <= 2, ((d <= 1).mean(), (d <= 1)[ring].mean(), d.max())
+    for mode in ('edge', 'reflect'):
+        res_m = O.conv2d_fwd(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)), mode=mode), w, b, 'VALID', None)
+        dm = np.abs(O.saturate_u8(sd + res_m)[0].astype(np.int64) - f['sr'].astype(np.int64))
+        assert (dm <= 1)[ring].mean() <= 0.75 and dm.max() >= 10, (mode, (dm <= 1)[ring].mean(), dm.max())
+        assert (dm[1:-1, 1:-1] == dsr[1:-1, 1:-1]).all()                # (the padding only reaches the border ring)
+
+
+def test_p7_the_whole_conv1_image_from_the_reference_sd_image():
+    """model_vdsr.py:62-76, the input layer (3 -> 64, ReLU) on the whole 256 x 256 image: the reference's conv.1.png (64
+    maps) predicted from its sd_image.png.  Zero SAME padding: every byte within one level, >= 97 % of the 4.2 million
+    bytes EXACT, all 1,020 x 64 border bytes (out of sample) within one level; edge padding: fewer than half of them."""
+    z, f, ring = p7_full20()
+    conv1 = np.load(os.path.join(GOLDEN, 'pin_p7_layer1_full.npz'))['conv1'].astype(np.int64)
+    x = p7_decode(f['sd'])[None]
+    w, b = z['w1'].astype(np.float64), z['b1'].astype(np.float64)
+    d = np.abs(O.saturate_u8(O.conv2d_fwd(x, w, b, 'SAME', 'relu'))[0].astype(np.int64) - conv1)
+    assert d.max() <= 1 and (d == 0).mean() >= 0.97, (d.max(), (d == 0).mean())
+    de = np.abs(O.saturate_u8(O.conv2d_fwd(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)), mode='edge'), w, b, 'VALID', 'relu'))[0].astype(np.int64) - conv1)
+    assert (de <= 1)[ring].mean() <= 0.5 and de.max() >= 20, ((de <= 1)[ring].mean(), de.max())
