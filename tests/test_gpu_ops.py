@@ -218,6 +218,32 @@ def test_subpixel_random_shapes_every_kernel_route(ops):
         assert torch.equal(back.view(torch.int32), t.view(torch.int32)), (n, h, w, c, r)
 
 
+def test_subpixel_buffers_aligned_to_16_bytes_only(ops):
+    """The pipelined kernel shifts its output-side lane assignment so that every store instruction starts on a 128-byte
+    line; the shift comes from the ACTUAL address of each chunk.  Input and output placed 16, 32, 80 bytes off a line
+    boundary (all the C ABI asks for is 16-byte alignment), several chunks per workgroup."""
+    rng = np.random.default_rng(5)
+    for (n, h, w, c, r) in [(256, 41, 41, 3, 3), (3, 17, 17, 3, 4), (40, 20, 33, 1, 2)]:
+        bits = rng.integers(0, 1 << 32, size=(n, h, w, c * r * r), dtype=np.uint64).astype(np.uint32)
+        numel = bits.size
+        ref = O.depth_to_space(bits[::7], r)
+        for off_in, off_out in ((4, 0), (0, 8), (20, 12), (8, 28)):
+            src = torch.zeros(numel + 64, dtype=torch.float32, device='cuda')
+            dst = torch.full((numel + 64,), float('nan'), dtype=torch.float32, device='cuda')
+            x = src[off_in:off_in + numel].view(n, h, w, c * r * r)
+            x.view(torch.int32).copy_(torch.from_numpy(bits.view(np.int32)))
+            out = dst[off_out:off_out + numel].view(n, h * r, w * r, c)
+            ops.depth_to_space(x, r, out=out)
+            np.testing.assert_array_equal(out[::7].view(torch.int32).cpu().numpy().view(np.uint32), ref)
+            # nothing outside the output range was touched
+            assert torch.isnan(dst[:off_out]).all() and torch.isnan(dst[off_out + numel:]).all()
+            back = src.clone()
+            back_view = back[off_in:off_in + numel].view(n, h, w, c * r * r)
+            back_view.zero_()
+            ops.space_to_depth(out, r, out=back_view)
+            assert torch.equal(back_view.view(torch.int32), x.view(torch.int32))
+
+
 def test_subpixel_full_size_roundtrip(ops):
     """north-star bandwidth shape [256,41,41,27] <-> [256,123,123,3]: d2s o s2d = id, and a
     checksum of checksums against the oracle's index map on a strided sample."""
