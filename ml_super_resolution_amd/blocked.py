@@ -166,12 +166,21 @@ class BlockedConv(object):
         ops.subsample2_bwd(dpre.contiguous().view(cob * n, h, w, co), 1, 1, out=full.view(cob * n, 2 * h, 2 * w, co))
         return full
 
-    def dgrad(self, dpre, mask=None, mask_act=None):
+    def full_res(self, dpre):
+        """The zero-stuffed gradient that wgrad() and dgrad() of a stride-2 layer both start from: a caller that needs
+        both computes it once and passes it as `stuffed` (one launch and one full-size write instead of two).  None where
+        the layer does not need it."""
+        if self.stride == 1:
+            return None
+        return self._full_res(dpre)
+
+    def dgrad(self, dpre, mask=None, mask_act=None, stuffed=None):
         """dpre [COB, N, OH, OW, co] (gradient w.r.t. the layer's pre-activation output) -> dx [CIB, N, H, W, ci],
         the gradient w.r.t. the layer's input.  mask / mask_act: the layer's INPUT as saved (the post-activation
         output of the layer below) and that layer's activation -- the result is then already multiplied by the
-        activation gradient (ReluGrad / leaky-ReLU gradient), fused into the launch where the kernel allows."""
-        dp = self._full_res(dpre)
+        activation gradient (ReluGrad / leaky-ReLU gradient), fused into the launch where the kernel allows.
+        stuffed: full_res(dpre) if the caller already has it."""
+        dp = stuffed if stuffed is not None else self._full_res(dpre)
         _, n, h, w, _ = dp.shape
         dx = torch.empty((self.cib, n, h, w, self.ci), dtype=torch.float32, device=dp.device)
         if self._wide_ok(w):
@@ -189,8 +198,8 @@ class BlockedConv(object):
                 ops.act_bwd(dx[ib], mask[ib], mask_act, out=dx[ib])
         return dx
 
-    def wgrad(self, x, dpre):
-        """Fills self.dw / self.db from the layer input x [CIB, N, H, W, ci] and dpre."""
+    def wgrad(self, x, dpre, stuffed=None):
+        """Fills self.dw / self.db from the layer input x [CIB, N, H, W, ci] and dpre (stuffed: full_res(dpre) if at hand)."""
         if self._true_stride2(x.shape[2], x.shape[3]):
             need = max(ops.bwd_filter_workspace_bytes(x[0].shape, self.w[0, 0].shape, 'same', stride=2), 16)
             ws = self._scratch.get('ws')
@@ -199,7 +208,7 @@ class BlockedConv(object):
             ops.conv2d_bwd_filter(x[0], dpre[0].contiguous(), self.w[0, 0].shape, 'same', dw=self.dw[0, 0], dbias=self.db, workspace=ws,
                                   stride=2)
             return
-        dp = self._full_res(dpre)
+        dp = stuffed if stuffed is not None else self._full_res(dpre)
         if self._wide_ok(x.shape[3]) and x.is_contiguous() and dp.is_contiguous() and self.dw.is_contiguous():
             _, n, h, w, _ = x.shape
             need = ops.conv3x3_blocked_bwd_filter_workspace_bytes(n, h, w, self.cib, self.cob)

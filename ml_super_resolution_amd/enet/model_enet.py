@@ -273,12 +273,13 @@ class Discriminator(object):
                 dpre = g
             else:
                 dpre = ops.act_bwd(g.contiguous(), y, 'lrelu', out=torch.empty_like(y))
+            stuffed = c.full_res(dpre)          # stride-2 layers: the zero-stuffed gradient, once for both gradients
             if want_dw:
-                c.wgrad(acts[i], dpre)
+                c.wgrad(acts[i], dpre, stuffed=stuffed)
             if i == 0 and not want_dx:
                 return None
             # the activation gradient of layer i - 1 (whose output acts[i] is this layer's input) rides in the launch
-            g = c.dgrad(dpre, mask=acts[i] if i > 0 else None, mask_act='lrelu' if i > 0 else None)
+            g = c.dgrad(dpre, mask=acts[i] if i > 0 else None, mask_act='lrelu' if i > 0 else None, stuffed=stuffed)
             masked = i > 0
         return to_nhwc(g)
 
