@@ -226,7 +226,7 @@ def extras(model, dev, stream, x64, y64, px):
         copy()
     cms = min(hip_event_time_ms(copy, 10 * pairs, stream) for _ in range(3))
     cgbps = nbytes / (cms * 1e-3) / 1e9
-    out['subpixel'] = {'bound': 'hbm', 'kernel': 'subpixel_pipe_kernel (standalone depth-to-space [256,41,41,27] -> [256,123,123,3])',
+    out['subpixel'] = {'bound': 'hbm', 'kernel': 'subpixel_even_kernel (standalone depth-to-space [256,41,41,27] -> [256,123,123,3])',
                        'launch_us': round(ms * 1e3, 2), 'bytes': nbytes, 'achieved': round(gbps, 1), 'peak': 8000.0,
                        'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4), 'rotating_pairs': pairs,
                        'copy_ceiling_gbps': round(cgbps, 1), 'copy_ceiling_us': round(cms * 1e3, 2),

@@ -7,8 +7,10 @@ constexpr int kReduceBlocks = 1024;  // partial slots a reduction may use (srx_r
 
 // chunk_kb: a chunk grows while twice its size stays within this many KiB; db: two LDS buffers (software pipeline);
 // grid: cap of the persistent grid; depth: chunks of loads in flight per workgroup (0 = automatic);
-// throttle: requests a wave keeps in flight (0 = counted waits only)
-struct SubpixelTune { int chunk_kb, db, grid, depth, throttle; };
+// throttle: requests a wave keeps in flight (0 = counted waits only, < 0 = the launcher's choice); even: 0 = subpixel_pipe_kernel's chunks of 4 blocks,
+// 1 = subpixel_even_kernel (chunks of any whole number of blocks) where a workgroup needs at most two trips,
+// 1 + t = that kernel with at least t trips, whatever their number
+struct SubpixelTune { int chunk_kb, db, grid, depth, throttle, even; };
 hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int C, int r, bool inverse,
                            const SubpixelTune& tune, hipStream_t s);
 hipError_t launch_stream_copy(const float* in, float* out, size_t bytes, hipStream_t s);

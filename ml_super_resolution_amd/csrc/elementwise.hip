@@ -144,6 +144,18 @@ struct SubpixelIndex {
     }
     // the four sources of float4 slot i of a chunk of c4 float4s, in the rotated order of the gather: entry e is the
     // source of element (e + rot) % 4; slots beyond the chunk get 0
+    // the same for four consecutive positions o0 .. o0+3 that need not start a float4 of the chunk (subpixel_even_kernel:
+    // the output side is aligned to the 128-byte lines of global memory, not to the chunk); ok = all four inside the chunk
+    __device__ __forceinline__ void rotated_at(int o0, bool ok, int rot, int (&out)[4]) const {
+        int t[4];
+        four(ok ? o0 : 0, t);
+        const bool r1 = rot & 1, r2 = rot & 2;
+        const int u0 = r1 ? t[1] : t[0], u1 = r1 ? t[2] : t[1], u2 = r1 ? t[3] : t[2], u3 = r1 ? t[0] : t[3];
+        out[0] = ok ? (r2 ? u2 : u0) : 0;
+        out[1] = ok ? (r2 ? u3 : u1) : 0;
+        out[2] = ok ? (r2 ? u0 : u2) : 0;
+        out[3] = ok ? (r2 ? u1 : u3) : 0;
+    }
     __device__ __forceinline__ void rotated(int i, int c4, int rot, int (&out)[4]) const {
         int t[4];
         four(4 * i, t);
@@ -333,6 +345,146 @@ void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
     }
 }
 
+// EVEN chunks.  subpixel_pipe_kernel's chunks are whole multiples of 4 blocks (so that every chunk starts a float4):
+// 2,624 chunks of 17.7 KB at [256,41,41,27], i.e. three trips for 576 of the 1,024 persistent workgroups and two for the
+// rest, and two LDS buffers of 17.7 KB are all that fits four workgroups per CU.  What a streaming kernel of this shape
+// pays for is the number of TRIPS (scripts/d2s_direct_ubench.hip: the pipe kernel's structure as a copy 16.2 us, three
+// equal trips of 15 KB 16.8 us, four of 11 KB 17.8 us -- and TWO trips of 22.6 KB for every workgroup 15.3 us, below
+// the plain one-round copy).  Here a chunk is ANY whole number of blocks: the tensor's `nblocks` blocks are dealt out
+// as `nchunks` = trips * grid chunks of q or q+1 blocks, chunk c -> workgroup c % grid.
+//  * A chunk starts at any 4-byte offset: its 16-byte loads go out from there (source alignment is free: 15.5 us
+//    either way, same benchmark) and the chunk sits at offset 0 of ONE LDS buffer (a chunk of up to 32 KB; the next chunk's
+//    loads wait in registers, as before).
+//  * The output side is aligned to the 128-byte lines of global memory instead: float4 slot j of a workgroup is the
+//    16 bytes at line_base + 16 j, i.e. positions 4 j - sf .. + 3 of the chunk (sf = floats between the line boundary below
+//    the chunk and the chunk, < 32).  Slots entirely inside the chunk are gathered and stored as before; the at most
+//    two float4s a chunk shares with its neighbours are written float by float by one lane each.
+//  * sf and the chunk length differ from chunk to chunk, so the gather table is computed per chunk -- between issuing
+//    the chunk's loads and the gather of the chunk before it, i.e. under the loads' latency.
+template <int KMAX, int THR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))   // four workgroups per CU: <= 128 registers
+void subpixel_even_kernel(const float* __restrict__ in, float* __restrict__ out, size_t total, int nchunks, int q, int rem,
+                          int lds_floats, SubpixelGeom geo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [lds_floats] + [256][4] dummy slots
+    const int G = gridDim.x;
+    const int tid = threadIdx.x;
+    const int lane_off = tid * 16;
+    const SubpixelIndex src_of(geo);
+    const int rot = (tid >> 3) & 3;
+    const bool r1 = rot & 1, r2 = rot & 2;
+    auto throttle = [&]() {
+        if constexpr (THR == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (THR == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if constexpr (THR == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (THR == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (THR == 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    };
+    struct Chunk { size_t S; int L, sf; };   // first float, floats, floats between the 128-byte line below out + S and out + S
+    auto chunk_of = [&](int c) {
+        Chunk k;
+        const int b0 = c * q + (c < rem ? c : rem);                    // the first `rem` chunks have q + 1 blocks
+        k.S = (size_t)b0 * (size_t)geo.B;
+        k.L = (q + (c < rem ? 1 : 0)) * geo.B;
+        k.sf = (int)((reinterpret_cast<uintptr_t>(out + k.S) & 127u) >> 2);
+        return k;
+    };
+    u32x4v v[KMAX];
+    // whole float4s from the chunk's first float on; the last one may reach up to 3 floats into the next chunk, except at
+    // the end of the tensor: there the ragged floats are fetched one by one (to_lds)
+    auto whole4 = [&](const Chunk& ch) { const int up = (ch.L + 3) & ~3; return ch.S + (size_t)up <= total ? up : (ch.L & ~3); };
+    auto issue = [&](const Chunk& ch, bool throttled) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + ch.S), 0, (unsigned)whole4(ch) * 4u, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + k * 4096, 0, 2 /* nt */);
+            if (throttled) throttle();
+        }
+    };
+    auto to_lds = [&](const Chunk& ch) {
+        const int w4 = whole4(ch), n4 = w4 >> 2, dummy = (lds_floats >> 2) + tid;
+        u32x4v* buf4 = reinterpret_cast<u32x4v*>(lds);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const int j = k * 256 + tid; buf4[j < n4 ? j : dummy] = v[k]; }
+        if (w4 < ch.L && tid < ch.L - w4) lds[w4 + tid] = in[ch.S + w4 + tid];      // (the tensor's last chunk only)
+    };
+    auto table = [&](const Chunk& ch, unsigned (&spk)[KMAX][2]) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int o0 = 4 * (k * 256 + tid) - ch.sf;
+            int t[4];
+            src_of.rotated_at(o0, o0 >= 0 && o0 + 4 <= ch.L, rot, t);
+            spk[k][0] = (unsigned)(t[0] * 4) | ((unsigned)(t[1] * 4) << 16);
+            spk[k][1] = (unsigned)(t[2] * 4) | ((unsigned)(t[3] * 4) << 16);
+        }
+    };
+    auto drain = [&](const Chunk& ch, const unsigned (&spk)[KMAX][2]) {
+        float* line = out + ch.S - ch.sf;                                  // (128-byte aligned)
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(line, 0, (unsigned)(ch.sf + ch.L) * 4u, 0x00020000);
+        const char* bytes = reinterpret_cast<const char*>(lds);
+        constexpr int GB = 3;   // float4s gathered per batch: their LDS reads are issued together (one latency per batch)
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += GB) {
+            float g[GB][4];
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < KMAX; ++k) {
+                g[k - k0][0] = *reinterpret_cast<const float*>(bytes + (spk[k][0] & 0xffffu));
+                g[k - k0][1] = *reinterpret_cast<const float*>(bytes + (spk[k][0] >> 16));
+                g[k - k0][2] = *reinterpret_cast<const float*>(bytes + (spk[k][1] & 0xffffu));
+                g[k - k0][3] = *reinterpret_cast<const float*>(bytes + (spk[k][1] >> 16));
+            }
+#pragma unroll
+            for (int k = k0; k < k0 + GB && k < KMAX; ++k) {
+                const f32x4 o = unrotate4(g[k - k0][0], g[k - k0][1], g[k - k0][2], g[k - k0][3], r1, r2);
+                const int j = k * 256 + tid, o0 = 4 * j - ch.sf;
+                // a float4 not entirely inside the chunk: an offset past the resource, the store is dropped
+                const unsigned off = (o0 >= 0 && o0 + 4 <= ch.L) ? (unsigned)j * 16u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), ro, off, 0, 2);
+                throttle();
+            }
+        }
+        // the float4s shared with the neighbouring chunks: one lane each, float by float
+        const int jh = ch.sf >> 2, jt = (ch.sf + ch.L) >> 2;
+        if ((tid == 0 && (ch.sf & 3)) || (tid == 64 && ((ch.sf + ch.L) & 3))) {
+            const int o0 = 4 * (tid == 0 ? jh : jt) - ch.sf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = o0 + e;
+                if (o >= 0 && o < ch.L) out[ch.S + o] = lds[src_of(o)];
+            }
+        }
+    };
+    int c = blockIdx.x;
+    if (c >= nchunks) return;
+    Chunk cur = chunk_of(c), nxt = cur;
+    // (the first chunk's loads are not throttled -- the wave goes on to its index arithmetic, not to more requests;
+    // throttled and interleaved with the arithmetic: 17.2 instead of 16.4 us)
+    issue(cur, false);
+    unsigned tab[KMAX][2], tab_n[KMAX][2];
+    table(cur, tab);
+    for (;;) {
+        lds_barrier();                       // every wave is done gathering the chunk before
+        to_lds(cur);
+        const bool more = c + G < nchunks;
+        if (more) {
+            nxt = chunk_of(c + G);
+            // (chunks G apart often have the same length and the same offset into a line: the table carries over)
+            issue(nxt, true);      // (unthrottled: 17.2 instead of 16.4 us)
+            if (nxt.L != cur.L || nxt.sf != cur.sf) {
+                table(nxt, tab_n);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) { tab_n[k][0] = tab[k][0]; tab_n[k][1] = tab[k][1]; }
+            }
+        }
+        lds_barrier();
+        drain(cur, tab);
+        if (!more) break;
+        c += G; cur = nxt;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { tab[k][0] = tab_n[k][0]; tab[k][1] = tab_n[k][1]; }
+    }
+}
+
 // One chunk per workgroup (grid = number of full chunks), one LDS buffer: the hardware's workgroup dispatcher does the
 // load balancing and seven workgroups share a CU, each with its chunk's loads in flight while it computes its gather
 // indices.  The index computation is paid per chunk instead of per persistent workgroup -- on the otherwise idle
@@ -439,7 +591,7 @@ static void launch_subpixel_pipe_t(int depth, int grid, size_t lds, hipStream_t 
 template <int K>
 static void launch_subpixel_pipe(int depth, int thr, int grid, size_t lds, hipStream_t s, const float* in, float* out, int nfull, int chunk,
                                  const SubpixelGeom& geo) {
-    switch (thr) {
+    switch (thr < 0 ? 3 : thr) {
         case 0: launch_subpixel_pipe_t<K, 0>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
         case 2: launch_subpixel_pipe_t<K, 2>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
         case 4: launch_subpixel_pipe_t<K, 4>(depth, grid, lds, s, in, out, nfull, chunk, geo); break;
@@ -460,6 +612,48 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
     // RB blocks per chunk: chunk must be a multiple of 4 floats so every chunk start is 16-B aligned
     size_t RB = 4;
     if (B % 4 == 0) RB = 1; else if (B % 2 == 0) RB = 2;
+    // even chunks of whole blocks (subpixel_even_kernel): a tensor of whole float4s with at least a few blocks per CU
+    // whose block fits 8 float4 slots per thread beside the output side's shift
+    constexpr size_t kEvenMaxFloats = 8 * 1024 - 34;
+    const size_t nblocks = (size_t)N * H;
+    size_t even_trips = 0, even_grid = 0;
+    if (kn.even && total % 4 == 0 && nblocks >= 512 && nblocks < (1u << 30) && B <= kEvenMaxFloats) {
+        const size_t cap = (size_t)(kn.grid > 0 ? kn.grid : 1024);
+        even_grid = nblocks < cap ? nblocks : cap;
+        even_trips = kn.even > 1 ? (size_t)kn.even - 1 : 1;   // (SRX_SUBPIXEL_EVEN = 1 + trips: at least that many trips)
+        auto max_blocks = [&](size_t t) { return (nblocks + even_grid * t - 1) / (even_grid * t); };
+        while (max_blocks(even_trips) > 1 && max_blocks(even_trips) * B > kEvenMaxFloats) ++even_trips;
+        // One LDS buffer: its barrier phases are not hidden behind a second buffer's traffic.  Up to two trips per
+        // workgroup that is the better trade (16.5 against 16.9 us at [256,41,41,27], 18.3 against 19.6 at [128,64,64,27]);
+        // from three trips on subpixel_pipe_kernel's two buffers win (28.1 against 27.6 us at [256,41,41,48], 69.5 against
+        // 62.5 at [1024,41,41,27]: scripts/time_d2s.py shapes).
+        if (even_trips > 2 && kn.even == 1) even_trips = 0;
+    }
+    if (even_trips) {
+        const SubpixelGeom geo = subpixel_geom(W, rC, r, inverse);
+        const size_t grid = even_grid, trips = even_trips;
+        const size_t nchunks = grid * trips < nblocks ? grid * trips : nblocks;
+        const int q = (int)(nblocks / nchunks), rem = (int)(nblocks % nchunks);
+        const size_t lmax = (size_t)(q + (rem ? 1 : 0)) * B;
+        const int lds_floats = (int)((lmax + 3) & ~(size_t)3);
+        const size_t lds_bytes = (size_t)lds_floats * 4 + 4096;
+        const int kneed = (int)(((lmax + 31 + 3) / 4 + 255) / 256);
+        // (measured at [256,41,41,27], alternating runs on three boxes: 16.4-16.6 us with 2 requests per wave in flight, 16.8-17.2
+        // with 3; subpixel_pipe_kernel -- three trips of smaller chunks for half of the workgroups -- has its optimum at 3.
+        // Eight waves per workgroup with one request each: 16.5-16.8.)
+        const int thr = kn.throttle >= 0 ? kn.throttle : 2;
+#define SRX_SUBPIXEL_EVEN_T(K, T) hipLaunchKernelGGL((subpixel_even_kernel<K, T>), dim3((unsigned)grid), dim3(256), lds_bytes, s, in, out, total, (int)nchunks, q, rem, lds_floats, geo)
+#define SRX_SUBPIXEL_EVEN(K) case K: switch (thr) { case 0: SRX_SUBPIXEL_EVEN_T(K, 0); break; case 1: SRX_SUBPIXEL_EVEN_T(K, 1); break; \
+            case 3: SRX_SUBPIXEL_EVEN_T(K, 3); break; case 4: SRX_SUBPIXEL_EVEN_T(K, 4); break; default: SRX_SUBPIXEL_EVEN_T(K, 2); break; } break;
+        switch (kneed) {
+            SRX_SUBPIXEL_EVEN(1) SRX_SUBPIXEL_EVEN(2) SRX_SUBPIXEL_EVEN(3) SRX_SUBPIXEL_EVEN(4)
+            SRX_SUBPIXEL_EVEN(5) SRX_SUBPIXEL_EVEN(6) SRX_SUBPIXEL_EVEN(7) SRX_SUBPIXEL_EVEN(8)
+            default: return hipErrorInvalidValue;
+        }
+#undef SRX_SUBPIXEL_EVEN
+#undef SRX_SUBPIXEL_EVEN_T
+        return hipGetLastError();
+    }
     if (RB * B * 4 <= lds_cap && B < (1u << 20)) {
         const SubpixelGeom geo = subpixel_geom(W, rC, r, inverse);
         const size_t target = (size_t)kn.chunk_kb * 1024;

@@ -21,7 +21,7 @@ thread_local char g_err[512] = "";
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
     int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe;
-    int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle;
+    int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
 };
@@ -42,7 +42,8 @@ Knobs read_knobs() {
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
     k.subpixel_grid = env_int("SRX_SUBPIXEL_GRID", 0);
     k.subpixel_depth = env_int("SRX_SUBPIXEL_DEPTH", 0);
-    k.subpixel_throttle = env_int("SRX_SUBPIXEL_THROTTLE", 3);   // requests per wave in flight (0: unbounded; built: 2-6, 8)
+    k.subpixel_throttle = env_int("SRX_SUBPIXEL_THROTTLE", -1);  // requests per wave in flight (0: unbounded; -1: the launcher's choice)
+    k.subpixel_even = env_int("SRX_SUBPIXEL_EVEN", 1);           // 0: chunks of 4 blocks (subpixel_pipe_kernel); 1 + t: t trips
     k.trace = nullptr;
     k.dbg = 0;
 #ifdef SRX_TRACE
@@ -724,7 +725,7 @@ static int subpixel(const float* in, float* out, int N, int H, int W, int C, int
     if (in == out) return fail(SRX_ERR_BAD_ARG, "sub-pixel map cannot run in place");
     if (N == 0 || H == 0 || W == 0) return SRX_OK;
     const SubpixelTune tune = {knobs().subpixel_chunk_kb, knobs().subpixel_db,
-                               knobs().subpixel_grid > 0 ? knobs().subpixel_grid : 4 * cu_count(), knobs().subpixel_depth, knobs().subpixel_throttle};
+                               knobs().subpixel_grid > 0 ? knobs().subpixel_grid : 4 * cu_count(), knobs().subpixel_depth, knobs().subpixel_throttle, knobs().subpixel_even};
     SRX_CHECK_LAUNCH(launch_subpixel(in, out, N, H, W, C, r, inv, tune, (hipStream_t)stream), "sub-pixel map");
 }
 

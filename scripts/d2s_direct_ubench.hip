@@ -98,6 +98,93 @@ __global__ __launch_bounds__(256) void scatter_x(const float* __restrict__ in, f
     }
 }
 
+
+// ---- is the map's chunking paying for its IMBALANCE?  2,624 chunks over 1,024 persistent workgroups = 3 chunks for 576
+// of them and 2 for the rest.  The map's structure as a copy (d2s_ubench's V3/W3: depth-1 prefetch, at most 3 requests
+// per wave, optionally through LDS with an identity gather), chunk c of workgroup g = g + c * G (STRIDED) or
+// g * per + c (CONTIG: every workgroup exactly `per` chunks).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int KMAX, int THR, bool LDS, bool CONTIG>
+__global__ __launch_bounds__(256) void chunked_bal(const float* __restrict__ in, float* __restrict__ out, int nchunks, int chunk_floats, int per) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = gridDim.x;
+    int c = CONTIG ? blockIdx.x * per : blockIdx.x;
+    const int cend = CONTIG ? min(c + per, nchunks) : nchunks, cstep = CONTIG ? 1 : G;
+    if (c >= cend) return;
+    const int c4 = chunk_floats >> 2;
+    auto throttle = [&]() {
+        if (THR == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (THR == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (THR == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (THR == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+    f32x4 v[KMAX];
+    int idx[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { const int i = k * 256 + threadIdx.x; idx[k] = i < c4 ? i : c4 - 1; }
+    auto issue = [&](int chunk) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + (size_t)chunk * c4;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { v[k] = __builtin_nontemporal_load(src + idx[k]); throttle(); }
+    };
+    issue(c);
+    int p = 0;
+    for (; c < cend; c += cstep, p ^= 1) {
+        f32x4 w[KMAX];
+        if (LDS) {
+            f32x4* buf4 = reinterpret_cast<f32x4*>(lds + p * chunk_floats);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) buf4[idx[k]] = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) w[k] = v[k];
+        }
+        if (c + cstep < cend) issue(c + cstep);
+        if (LDS) {
+            lds_barrier();
+            const float* buf = lds + p * chunk_floats;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[k][e] = buf[4 * idx[k] + e];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(out) + (size_t)c * c4;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k * 256 + (int)threadIdx.x < c4) __builtin_nontemporal_store(w[k], dst + idx[k]);
+            throttle();
+        }
+    }
+}
+
+
+// plain one-round copy (d2s_ubench's A1) for the alignment question below
+template <int KMAX>
+__global__ __launch_bounds__(256) void copy_a(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t n4) {
+    const size_t per = (size_t)KMAX * 256;
+    for (size_t base = (size_t)blockIdx.x * per; base < n4; base += (size_t)gridDim.x * per) {
+        f32x4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < n4) v[k] = __builtin_nontemporal_load(in + i); }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < n4) __builtin_nontemporal_store(v[k], out + i); }
+    }
+}
+// the same with bounds-checked buffer loads whose base is only 4-byte aligned
+template <int KMAX>
+__global__ __launch_bounds__(256) void copy_buf_src(const float* __restrict__ in, float* __restrict__ out, unsigned bytes) {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+    const unsigned per = KMAX * 4096u;
+    for (unsigned base = blockIdx.x * per; base < bytes; base += gridDim.x * per) {
+        u32x4v v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { v[k] = __builtin_amdgcn_raw_buffer_load_b128(ri, base + k * 4096 + threadIdx.x * 16, 0, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { __builtin_amdgcn_raw_buffer_store_b128(v[k], ro, base + k * 4096 + threadIdx.x * 16, 0, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+}
+
 __global__ void fill_iota(unsigned* p, unsigned n) { for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = i * 2654435761u; }
 
 int main() {
@@ -137,6 +224,7 @@ int main() {
     };
     auto grid = [&](int k) { return dim3((nfl + k * 1024 - 1) / (k * 1024)); };
 #define RUN(name, kern, K) timeit(name, [&](int i) { hipLaunchKernelGGL(kern, grid(K), dim3(256), 0, 0, in[i], out[i], nfl); })
+    if (getenv("D2S_DIRECT")) {
     RUN("X1 gather, 4 float4/thread, all loads then all stores", (gather_x<4, 0>), 4);
     RUN("X1 gather, 6 float4/thread", (gather_x<6, 0>), 6);
     RUN("X1 gather, 8 float4/thread", (gather_x<8, 0>), 8);
@@ -148,5 +236,46 @@ int main() {
     RUN("X2 scatter, 8 float4/thread", (scatter_x<8, 0>), 8);
     RUN("X2n scatter, 6 float4/thread, nontemporal stores", (scatter_x<6, 2>), 6);
     RUN("X2s scatter, 6 float4/thread, one float4's stores at a time", (scatter_x<6, 1>), 6);
+    }
+
+    {   // imbalance: copies in the map's structure (no permutation: not checked against the map)
+        auto timecopy = [&](const char* name, auto launch) {
+            for (int i = 0; i < 2 * P; ++i) launch(i % P);
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 80; ++i) launch(i % P);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 80 < best) best = ms / 80;
+            }
+            CK(hipGetLastError());
+            printf("%-78s %6.2f us  %5.2f TB/s\n", name, best * 1e3, 2.0 * nfl * 4 / (best * 1e-3) / 1e12);
+        };
+        const int ca = 4608, na = (int)(nfl / ca);                 // 2,521 line-aligned chunks: 2.46 per workgroup, 3 at most
+        const size_t la = (size_t)ca * 8 + 4096;
+        timecopy("S3  strided chunks of 4608 floats, 1024 wgs (2 or 3 chunks each), no LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<5, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca, 0); });
+        timecopy("S3l the same through LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<5, 3, true, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], na, ca, 0); });
+        const int cb = 3776, nb = 3 * 1024;                         // 944 float4 (118 lines) x 3 per workgroup: 99.8 % of the tensor
+        timecopy("C3  contiguous: 3 chunks of 3776 floats for EVERY one of 1024 wgs, no LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<4, 3, false, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], nb, cb, 3); });
+        timecopy("C3l the same through LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<4, 3, true, true>), dim3(1024), dim3(256), la, 0, in[i], out[i], nb, cb, 3); });
+        timecopy("C3s 3 chunks of 3776 floats each, STRIDED over 1024 wgs, no LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<4, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nb, cb, 0); });
+        timecopy("C3sl the same through LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<4, 3, true, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nb, cb, 0); });
+        const int cc = 2832, nc = 4 * 1024;                         // 708 float4 x 4 per workgroup (99.8 %)
+        timecopy("C4s 4 chunks of 2832 floats each, strided, no LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<3, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nc, cc, 0); });
+        timecopy("C4sl the same through LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<3, 3, true, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nc, cc, 0); });
+        const int cd = 5664, nd = 2 * 1024;                         // 1416 float4 x 2 per workgroup
+        const size_t ld = (size_t)cd * 8 + 4096;
+        timecopy("C2s 2 chunks of 5664 floats each, strided, no LDS (LDS as for its double buffer: 3 wgs per CU!)", [&](int i) { hipLaunchKernelGGL((chunked_bal<6, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nd, cd, 0); });
+        (void)ld;
+
+        // 16-byte loads from a source that is only 4-byte aligned (chunks of whole blocks of 4428 bytes start 0/4/8/12 bytes into a float4)
+        timecopy("N0 copy A1 (8 float4/thread, one round), global ops, aligned", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)in[i], (f32x4*)out[i], (size_t)nfl / 4 - 8); });
+        timecopy("N1 ... source 4 bytes into a float4", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)(in[i] + 1), (f32x4*)out[i], (size_t)nfl / 4 - 8); });
+        timecopy("N2 ... source 12 bytes into a float4", [&](int i) { hipLaunchKernelGGL(copy_a<8>, dim3(1419), dim3(256), 0, 0, (const f32x4*)(in[i] + 3), (f32x4*)out[i], (size_t)nfl / 4 - 8); });
+        timecopy("N3 serialised buffer-op copy (6 float4/thread, 1892 wgs), aligned", [&](int i) { hipLaunchKernelGGL(copy_buf_src<6>, dim3(1892), dim3(256), 0, 0, in[i], out[i], (unsigned)(nfl * 4 - 128)); });
+        timecopy("N4 ... source base 4 bytes into a float4", [&](int i) { hipLaunchKernelGGL(copy_buf_src<6>, dim3(1892), dim3(256), 0, 0, in[i] + 1, out[i], (unsigned)(nfl * 4 - 128)); });
+        timecopy("N5 ... source base 8 bytes into a float4", [&](int i) { hipLaunchKernelGGL(copy_buf_src<6>, dim3(1892), dim3(256), 0, 0, in[i] + 2, out[i], (unsigned)(nfl * 4 - 128)); });
+    }
     return 0;
 }

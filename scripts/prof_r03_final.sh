@@ -16,5 +16,8 @@ scripts/prof_stats.sh r03_pat_d_after python3 scripts/time_enet_pat.py 64 3 128 
 python3 scripts/time_enet_pat.py 64 5 128 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_time_enet_pat.txt
 python3 scripts/time_enet_pat.py 4 3 512 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_time_enet_pat.txt
 python3 scripts/time_d2s.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_time_d2s_final.txt
+SRX_SUBPIXEL_EVEN=0 python3 scripts/time_d2s.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_time_d2s_final.txt
+python3 scripts/time_d2s.py shapes 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_time_d2s_shapes.txt
+SRX_SUBPIXEL_EVEN=0 python3 scripts/time_d2s.py shapes 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_time_d2s_shapes.txt
 python3 scripts/time_srcnn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_time_srcnn.txt
 python3 scripts/time_espcn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_time_espcn.txt

@@ -6,6 +6,7 @@ persistent workgroups -- the ceiling of a byte-moving kernel at this transfer si
 
   python scripts/time_d2s.py            one line for the current environment
   python scripts/time_d2s.py sweep      the tuning knobs, one fresh process each (they are read once per process)
+  python scripts/time_d2s.py shapes     other shapes of the map (both directions), current environment
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,8 +44,42 @@ def one():
           % (knobs or 'defaults', t1, by / t1 / 1e6, 100 * by / t1 / 1e6 / 8, t2, by / t2 / 1e6, t4, by / t4 / 1e6, t3, by / t3 / 1e6), flush=True)
 
 
+SHAPES = [(256, 41, 41, 3, 3), (256, 17, 17, 3, 3), (64, 85, 85, 3, 2), (256, 41, 41, 3, 4), (128, 64, 64, 3, 3), (1024, 41, 41, 3, 3),
+          (16, 360, 640, 3, 3), (32, 128, 128, 1, 3), (512, 24, 24, 3, 2), (8, 135, 240, 3, 4)]
+
+
+def shapes():
+    import torch
+    from ml_super_resolution_amd import ops
+    knobs = ' '.join('%s=%s' % (k, v) for k, v in os.environ.items() if k.startswith('SRX_SUBPIXEL')) or 'defaults'
+    for n, h, w, c, r in SHAPES:
+        by = 2 * n * h * w * c * r * r * 4
+        P = max(2, min(8, int(800e6 // by)))
+        bufs = [torch.rand((n, h, w, c * r * r), device='cuda') for _ in range(P)]
+        outs = [torch.empty((n, h * r, w * r, c), device='cuda') for _ in range(P)]
+
+        def run(fn, iters=60):
+            for i in range(2 * P): fn(i)
+            best = 1e9
+            for _ in range(3):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for i in range(iters): fn(i)
+                e.record(); e.synchronize()
+                best = min(best, s.elapsed_time(e) / iters * 1e3)
+            return best
+        t1 = run(lambda i: ops.depth_to_space(bufs[i % P], r, out=outs[i % P]))
+        t2 = run(lambda i: ops.space_to_depth(outs[i % P], r, out=bufs[i % P]))
+        t4 = run(lambda i: ops.stream_copy(bufs[i % P], outs[i % P]))
+        print('%-28s [%d,%d,%d,%d] r%d %6.1f MB  d2s %7.2f us %.2f TB/s | s2d %7.2f us %.2f TB/s | copy %7.2f us'
+              % (knobs, n, h, w, c * r * r, r, by / 1e6, t1, by / t1 / 1e6, t2, by / t2 / 1e6, t4), flush=True)
+        del bufs, outs
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+    if len(sys.argv) > 1 and sys.argv[1] == 'shapes':
+        shapes()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'sweep':
         for env in SWEEP:
             subprocess.check_call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, **env))
     else:

@@ -244,6 +244,37 @@ def test_subpixel_buffers_aligned_to_16_bytes_only(ops):
             assert torch.equal(back_view.view(torch.int32), x.view(torch.int32))
 
 
+def test_subpixel_even_chunks(ops):
+    """subpixel_even_kernel (tensors of whole float4s with >= 512 blocks whose workgroups need at most two trips): chunks of
+    q and q + 1 whole blocks starting at any 4-byte offset, one block of 12 floats per chunk (every float4 shared with a
+    neighbour), one and two trips, runs shorter than a float4 (r * C < 4), odd and even block lengths, the tensor's ragged
+    last chunk, outputs 16 / 48 / 112 bytes off a 128-byte line: bit-exact against the oracle's index map, both directions,
+    nothing written outside the output."""
+    rng = np.random.default_rng(77)
+    shapes = [(512, 1, 3, 1, 2), (16, 40, 7, 3, 3), (300, 7, 41, 3, 3), (64, 128, 30, 2, 2), (128, 64, 64, 3, 3), (100, 41, 20, 1, 1),
+              (33, 31, 24, 4, 3), (256, 41, 41, 3, 3), (64, 17, 12, 1, 2), (513, 4, 5, 4, 1)]
+    for (n, h, w, c, r) in shapes:
+        bits = rng.integers(0, 1 << 32, size=(n, h, w, c * r * r), dtype=np.uint64).astype(np.uint32)
+        numel = bits.size
+        assert numel % 4 == 0 and n * h >= 512
+        step = 1 if numel < 3000000 else 11
+        ref = O.depth_to_space(bits[::step], r)
+        for off_in, off_out in ((0, 0), (4, 12), (8, 28)):
+            src = torch.zeros(numel + 64, dtype=torch.float32, device='cuda')
+            dst = torch.full((numel + 64,), float('nan'), dtype=torch.float32, device='cuda')
+            x = src[off_in:off_in + numel].view(n, h, w, c * r * r)
+            x.view(torch.int32).copy_(torch.from_numpy(bits.view(np.int32)))
+            out = dst[off_out:off_out + numel].view(n, h * r, w * r, c)
+            ops.depth_to_space(x, r, out=out)
+            np.testing.assert_array_equal(out[::step].view(torch.int32).cpu().numpy().view(np.uint32), ref, err_msg=str((n, h, w, c, r, off_in, off_out)))
+            assert torch.isnan(dst[:off_out]).all() and torch.isnan(dst[off_out + numel:]).all()
+            back = torch.full((numel + 64,), float('nan'), dtype=torch.float32, device='cuda')
+            back_view = back[off_in:off_in + numel].view(n, h, w, c * r * r)
+            ops.space_to_depth(out, r, out=back_view)
+            assert torch.equal(back_view.view(torch.int32), x.view(torch.int32)), (n, h, w, c, r, off_in, off_out)
+            assert torch.isnan(back[:off_in]).all() and torch.isnan(back[off_in + numel:]).all()
+
+
 def test_subpixel_full_size_roundtrip(ops):
     """north-star bandwidth shape [256,41,41,27] <-> [256,123,123,3]: d2s o s2d = id, and a
     checksum of checksums against the oracle's index map on a strided sample."""
