@@ -266,7 +266,7 @@ int main() {
         timecopy("C4sl the same through LDS", [&](int i) { hipLaunchKernelGGL((chunked_bal<3, 3, true, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nc, cc, 0); });
         const int cd = 5664, nd = 2 * 1024;                         // 1416 float4 x 2 per workgroup
         const size_t ld = (size_t)cd * 8 + 4096;
-        timecopy("C2s 2 chunks of 5664 floats each, strided, no LDS (LDS as for its double buffer: 3 wgs per CU!)", [&](int i) { hipLaunchKernelGGL((chunked_bal<6, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nd, cd, 0); });
+        timecopy("C2s 2 chunks of 5664 floats each, strided, no LDS (4 wgs per CU)", [&](int i) { hipLaunchKernelGGL((chunked_bal<6, 3, false, false>), dim3(1024), dim3(256), la, 0, in[i], out[i], nd, cd, 0); });
         (void)ld;
 
         // 16-byte loads from a source that is only 4-byte aligned (chunks of whole blocks of 4428 bytes start 0/4/8/12 bytes into a float4)
