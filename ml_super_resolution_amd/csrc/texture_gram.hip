@@ -54,9 +54,10 @@ __device__ __forceinline__ void fill_normalised(float* tile, float* mrow, const 
         const int idx = first + k;
         const f32x4 v = *reinterpret_cast<const f32x4*>(xp + ((size_t)(idx >> 4) * W + (idx & 15)) * C + 4 * c4);
         const float m = group_sum<LPP>((v[0] + v[1]) + (v[2] + v[3])) / (float)C + eps;
+        const float im = 1.0f / m;            // (one division per lane and pixel, not four: the fill is VALU work beside the MFMAs)
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[e] / m;
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * im;
         *reinterpret_cast<f32x4*>(tile + k * LS + 4 * c4) = o;
         if (mrow && c4 == 0) mrow[k] = m;
     }
@@ -160,11 +161,12 @@ __global__ __launch_bounds__(256) void texture_gram_bwd_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < NJ; ++j) t += (alpha * acc[j][r]) * (tn[k * LSN + 16 * j + li] * m);
         t = group_sum<16>(t);
-        const float kk = t / ((float)C * m * m);
+        const float im = 1.0f / m;
+        const float kk = t * (im * im) * (1.0f / (float)C);
         const int idx = pb * 64 + k;
         float* o = dx + origin + ((size_t)(idx >> 4) * W + (idx & 15)) * C + li;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) o[16 * j] = (alpha * acc[j][r]) / m - kk;
+        for (int j = 0; j < NJ; ++j) o[16 * j] = (alpha * acc[j][r]) * im - kk;
     }
 }
 

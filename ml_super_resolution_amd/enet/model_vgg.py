@@ -120,9 +120,13 @@ class Vgg19(object):
             name = LAYER_NAMES[idx]
             if name in dtaps:
                 d = to_blocks(dtaps[name])
-                if masked:
-                    d = relu_grad(d, feats[name])
-                g = d if g is None else ops_add_(g, d)
+                if g is not None and masked:
+                    # g already carries this layer's ReluGrad and the tap does not: (y > 0) ? g + d : 0 in one pass
+                    g = ops.add_relu_grad(g.contiguous(), d.contiguous(), feats[name], out=g)
+                else:
+                    if masked:
+                        d = relu_grad(d, feats[name])
+                    g = d if g is None else ops_add_(g, d)
             if g is None:
                 continue
             below_name = LAYER_NAMES[idx - 1] if idx > 0 else 'input'
