@@ -1986,14 +1986,15 @@ struct WgradPairs {
     long part_pair_stride;       // floats of partials per pair
     int cob;                     // output blocks: pair = ib * cob + ob
 };
-template <int KH, int KW, int CINP, int NCH, int MINW>
+// STRIP: the column-strip body (rows too wide for one tile: the discriminator's 128 / 256-channel layers on 128- and 64-pixel rows)
+template <int KH, int KW, int CINP, int NCH, int MINW, bool STRIP>
 __global__ __launch_bounds__(256, MINW) void wgrad_lin_pairs_kernel(const WgradPairs q) {
     WgradArgs a = q.a;
     const int pair = blockIdx.y, ib = pair / q.cob, ob = pair - ib * q.cob;
     a.x += ib * q.x_pair_stride;
     a.dpre += ob * q.d_pair_stride;
     a.part += pair * q.part_pair_stride;
-    wgrad_lin_body<KH, KW, CINP, NCH, MINW, false>(a);
+    wgrad_lin_body<KH, KW, CINP, NCH, MINW, STRIP>(a);
 }
 
 

@@ -618,18 +618,23 @@ void blocked_desc(srx_conv_desc* d, int N, int H, int W) {
     memset(d, 0, sizeof(*d));
     d->N = N; d->H = H; d->W = W; d->Cin = 64; d->Cout = 64; d->KH = 3; d->KW = 3; d->stride = 1; d->pad_mode = SRX_PAD_SAME;
 }
-// One launch for all pairs needs the linear-walk kernel (full-width tiles, two workgroups per CU); G partials per pair so
-// that pairs x G fills the chip about once.
-bool pairs_route(const srx_conv_desc* d, const Plan& p, int pairs, int* G, size_t* lin_lds) {
+// One launch for all pairs needs the linear-walk kernel (two workgroups per CU; full-width tiles, or column strips under
+// the conditions of the single-layer entry point); G partials per pair so that pairs x G fills the chip about once.
+// Returns 0 (one launch per pair), 1 (full-width tiles) or 2 (column strips).
+int pairs_route(const srx_conv_desc* d, const Plan& p, int pairs, int* G, size_t* lin_lds) {
     *lin_lds = p.lds_bytes + 4 * (size_t)(p.cinp + 4) * 4;
-    const bool lin_ok = knobs().wgrad_lin && p.NTX == 1 && p.cinp == 64 && p.nch == 4 && d->W >= 4 && p.RS >= 8 &&
-                        p.RS == d->W + p.pad_l && (long)p.TH * d->W * 64 * 4 < (1L << 30) &&
-                        (long)d->H * d->W * 64 * 4 < (1L << 31) - 4096 && *lin_lds <= 80 * 1024;
+    const bool common = knobs().wgrad_lin && p.cinp == 64 && p.nch == 4 && d->W >= 4 && p.RS >= 8 && *lin_lds <= 80 * 1024 &&
+                        (long)d->H * d->W * 64 * 4 < (1L << 31) - 4096;
+    const bool lin_ok = common && p.NTX == 1 && p.RS == d->W + p.pad_l && (long)p.TH * d->W * 64 * 4 < (1L << 30);
+    const int wppp = 256 / (64 / 4);
+    const bool strip_ok = common && p.NTX > 1 && p.RS >= wppp && p.TW >= 4 && (d->W % p.TW == 0 || d->W % p.TW >= 4) &&
+                          p.RS <= 3 * wppp && (long)d->H * d->W * 64 * 4 < (1L << 30);
     int g = max_grid() / pairs;
     if (g < 1) g = 1;
     if (g > p.grid) g = p.grid;
     *G = g;
-    return lin_ok && pairs > 1 && pairs <= 65535;
+    if (pairs <= 1 || pairs > 65535) return 0;
+    return lin_ok ? 1 : (strip_ok ? 2 : 0);
 }
 }  // namespace
 
@@ -639,6 +644,7 @@ size_t srx_conv3x3_blocked_bwd_filter_workspace_bytes(int N, int H, int W, int s
     if (check_desc(&d) || staged_blocks <= 0 || produced_blocks <= 0) return 0;
     Plan p;
     if (make_plan(N, H, W, H, W, 64, 64, 3, 3, 1, 1, &p)) return 0;
+    wgrad_tile_for_linear_walk(&d, &p);
     int G;
     size_t lin_lds;
     const int pairs = staged_blocks * produced_blocks;
@@ -663,12 +669,16 @@ int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw,
     Plan p;
     rc = make_plan(N, H, W, H, W, 64, 64, 3, 3, 1, 1, &p);
     if (rc) return rc;
+    // (32-wide rows: the plan's 7 + 2 rows of 33 slots fill the 80-KiB budget to the last slot and the linear-walk kernel's
+    // zeroed slots no longer fit -- every pair would become its own launch; one row less, as on the single-layer entry)
+    wgrad_tile_for_linear_walk(&d, &p);
     const int pairs = staged_blocks * produced_blocks;
     const size_t blk = (size_t)N * H * W * 64, wn = (size_t)9 * 64 * 64;
     int G;
     size_t lin_lds;
-    if (!pairs_route(&d, p, pairs, &G, &lin_lds)) {
-        // one pair at a time on the single-layer entry point (column strips, odd shapes, a single pair)
+    const int route = pairs_route(&d, p, pairs, &G, &lin_lds);
+    if (!route) {
+        // one pair at a time on the single-layer entry point (odd shapes, a single pair)
         for (int ib = 0; ib < staged_blocks; ++ib)
             for (int ob = 0; ob < produced_blocks; ++ob) {
                 rc = srx_conv2d_bwd_filter(&d, x + ib * blk, dpre + ob * blk, dw + ((size_t)ib * produced_blocks + ob) * wn,
@@ -695,7 +705,7 @@ int srx_conv3x3_blocked_bwd_filter(const float* x, const float* dpre, float* dw,
     q.cob = produced_blocks;
     ConvKey k{3, 3, 64, 4, false};
     hipError_t err = hipSuccess;
-    if (!launch_wgrad_lin_pairs(k, q, G, pairs, lin_lds, (hipStream_t)stream, &err))
+    if (!launch_wgrad_lin_pairs(k, q, G, pairs, route == 2, lin_lds, (hipStream_t)stream, &err))
         return fail(SRX_ERR_UNSUPPORTED, "no pairs instance of the linear-walk wgrad kernel");
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "blocked wgrad launch failed: %s", hipGetErrorString(err));
     err = launch_reduce_partials_pairs((const float*)ws, G, a.part_stride, (int)wn, 64, dw, dbias, pairs, produced_blocks,

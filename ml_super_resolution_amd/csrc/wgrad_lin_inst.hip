@@ -16,9 +16,10 @@ bool launch_wgrad_lin_strip(const ConvKey& k, const WgradArgs& a, int grid, size
     return false;
 }
 // layers wider than 64 channels: all block pairs in one launch
-bool launch_wgrad_lin_pairs(const ConvKey& k, const WgradPairs& q, int grid, int pairs, size_t lds, hipStream_t s, hipError_t* err) {
+bool launch_wgrad_lin_pairs(const ConvKey& k, const WgradPairs& q, int grid, int pairs, bool strips, size_t lds, hipStream_t s, hipError_t* err) {
     if (k.kh == 3 && k.kw == 3 && k.cinp == 64 && k.nch == 4) {
-        *err = launch_with_lds(wgrad_lin_pairs_kernel<3, 3, 64, 4, 2>, q, grid, lds, s, pairs);
+        *err = strips ? launch_with_lds(wgrad_lin_pairs_kernel<3, 3, 64, 4, 2, true>, q, grid, lds, s, pairs)
+                      : launch_with_lds(wgrad_lin_pairs_kernel<3, 3, 64, 4, 2, false>, q, grid, lds, s, pairs);
         return true;
     }
     return false;

@@ -520,10 +520,15 @@ def test_even_filter_sizes_with_same_padding(k, cin, cout, h, w):
 
 
 @pytest.mark.parametrize('cib,cob,n,h,w', [(2, 4, 8, 16, 16), (4, 2, 16, 8, 8), (8, 8, 6, 4, 4), (1, 3, 3, 32, 32), (2, 2, 2, 9, 37),
-                                           (2, 1, 1, 6, 130), (1, 1, 2, 12, 12)])
+                                           (2, 1, 1, 6, 130), (1, 1, 2, 12, 12),
+                                           # 32-wide rows with enough of them for the planner's tallest tile (7 + 2 rows of 33 slots
+                                           # = the whole 80-KiB budget): the pairs launch takes one row less (round 3)
+                                           (2, 4, 8, 32, 32), (2, 2, 40, 32, 32),
+                                           # rows cut into column strips: all pairs in one launch of the strip body (round 3)
+                                           (2, 2, 4, 64, 64), (1, 2, 2, 20, 128), (2, 2, 1, 16, 100), (2, 3, 2, 7, 61)])
 def test_blocked_filter_gradient_all_pairs_in_one_launch(cib, cob, n, h, w):
-    """srx_conv3x3_blocked_bwd_filter (one launch over the block pairs + one reduction; per-pair launches where the
-    linear-walk kernel does not cover the shape: the 130-wide case, the single pair) against one srx_conv2d_bwd_filter
+    """srx_conv3x3_blocked_bwd_filter (one launch over the block pairs + one reduction -- full-width tiles or column strips;
+    per-pair launches where the linear-walk kernel does not cover the shape, and for a single pair) against one srx_conv2d_bwd_filter
     per pair and against the float64 sums."""
     from ml_super_resolution_amd import ops
     rng = np.random.default_rng(cib * 100 + cob * 10 + h)
