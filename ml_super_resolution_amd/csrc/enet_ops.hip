@@ -458,6 +458,113 @@ __global__ __launch_bounds__(256) void gemm_mfma_w64_kernel(const GemmArgs g, in
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMMs: M <= 16 rows against a large row-major matrix, one pass over the matrix at HBM speed.  The
+// discriminator's first dense layer at BASELINE config 5's tile size has 16 x 16 x 512 = 131,072 inputs x 1,024 units =
+// 537 MB of weights for a batch of 4-8 rows; the 64 x 64-tile kernel above reads them as 4-byte pieces of 64 bytes per
+// row (forward, 16 splits = 256 workgroups) or with a 4-KB stride between lanes (data gradient): 311-380 us = 1.4-1.7 TB/s.
+//  NN  C[m,n] = sum_k A[m,k] W[k,n]: a thread owns four columns (one 16-byte load per row of W), a workgroup 1,024
+//      columns and one K range whose slice of A sits in LDS (broadcast reads); split-K partials + the finish kernel above.
+//  NT  C[m,n] = sum_k A[m,k] W[n,k]: a wave owns 16 / MT rows of W at a time (16-byte loads along the row), A [MT][K] in
+//      LDS, per-lane partial sums for its 16 (row, m) results, then a transposing butterfly: in step o = 32, 16, 8, 4 a
+//      lane hands half of its values to lane ^ o and keeps the other half (8 + 4 + 2 + 1 exchanges instead of 16 x 6),
+//      two plain steps finish the sum over the remaining four lanes.
+// tf.layers.dense forward / tf.gradients: enet/enet/model_enet.py:148-154, 331-346.
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_nn_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float a_lds[];      // [MT][ksplit]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x * 1024 + tid * 4;
+    const int split = blockIdx.y;
+    const int k0 = split * g.ksplit;
+    const int k1 = (k0 + g.ksplit < g.K) ? k0 + g.ksplit : g.K;
+    const int kc = k1 - k0;                                              // (a multiple of 4: K and ksplit are)
+    for (int i = tid; i < MT * g.ksplit; i += 256) {
+        const int m = i / g.ksplit, k = i - m * g.ksplit;
+        a_lds[i] = (m < g.M && k < kc) ? g.A[(long)m * g.sam + (long)(k0 + k) * g.sak] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < g.N) {
+        const float* bp = g.B + (long)k0 * g.sbk + n;
+#pragma unroll 2
+        for (int k = 0; k < kc; k += 4) {
+            f32x4 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bp + (long)(k + u) * g.sbk));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(a_lds + m * g.ksplit + k);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m] += a[u] * b[u];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (m < g.M) *reinterpret_cast<f32x4*>(g.part + ((size_t)split * g.M + m) * g.N + n) = acc[m];
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(const GemmArgs g) {
+    constexpr int R = 16 / MT;                                         // rows of W per wave and trip
+    extern __shared__ __attribute__((aligned(16))) float a_lds[];      // [MT][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < MT * g.K; i += 256) {
+        const int m = i / g.K, k = i - m * g.K;
+        a_lds[i] = (m < g.M) ? g.A[(long)m * g.sam + (long)k * g.sak] : 0.f;
+    }
+    __syncthreads();
+    const long trips = ((long)g.N + R - 1) / R;
+    for (long t = (long)blockIdx.x * 4 + wave; t < trips; t += (long)gridDim.x * 4) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        const float* wrow[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long n = t * R + r;
+            wrow[r] = g.B + (n < g.N ? n : (long)g.N - 1) * g.sbn;        // (a surplus row re-reads the last one; never written)
+        }
+        for (int k = lane * 4; k < g.K; k += 256) {
+            f32x4 w[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wrow[r] + k));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(a_lds + m * g.K + k);
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r * MT + m] += (a[0] * w[r][0] + a[1] * w[r][1]) + (a[2] * w[r][2] + a[3] * w[r][3]);
+            }
+        }
+        // transposing butterfly: afterwards v[0] of lane l is value (l >> 2) summed over the lanes that differ from l in bits 2..5
+#pragma unroll
+        for (int o = 32, c = 8; c >= 1; o >>= 1, c >>= 1) {
+            const bool hi = lane & o;
+#pragma unroll
+            for (int i = 0; i < c; ++i) {
+                const float send = hi ? v[i] : v[i + c];
+                const float keep = hi ? v[i + c] : v[i];
+                v[i] = keep + __shfl_xor(send, o);
+            }
+        }
+        float sum = v[0];
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        // bits 5..2 of the lane chose the upper (1) or lower half at o = 32, 16, 8, 4: value index = those bits, high to low
+        const int idx = lane >> 2, r = idx / MT, m = idx - r * MT;
+        const long n = t * R + r;
+        if ((lane & 3) == 0 && n < g.N && m < g.M) {
+            float* c = g.C + (long)m * g.scm + n * g.scn;
+            const float out = g.alpha * sum;
+            *c = g.accumulate ? *c + out : out;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const GemmArgs g) {
     const size_t total = (size_t)g.M * g.N;
     SRX_GRID_STRIDE(i, total) {
@@ -618,14 +725,27 @@ int srx_column_sums(const float* a, float* out, int rows, int cols, int ld, srx_
     SRX_LAUNCHED("column_sums");
 }
 
-size_t srx_gemm_workspace_bytes(int M, int N, int K, int batch) {
-    if (batch != 1 || M <= 0 || N <= 0 || K <= 0) return 0;
+// split-K of the 64 x 64-tile kernel: 0 = none
+static long gemm_tile_splits(int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (tiles >= 128 || K < 512) return 0;
     long splits = (256 + tiles - 1) / tiles;
     if (splits > K / 64) splits = K / 64;
-    if (splits < 2) return 0;
-    return (size_t)splits * M * N * sizeof(float);
+    return splits < 2 ? 0 : splits;
+}
+// split-K of gemm_skinny_nn_kernel (M <= 16, a long K, whole float4s): K ranges of 256 or more, about two workgroups per CU
+static long gemm_skinny_nn_splits(int M, int N, int K) {
+    if (M > 16 || K < 4096 || (K & 3) || (N & 3) || N < 256) return 0;
+    const long nx = (N + 1023) / 1024;
+    long splits = 512 / nx;
+    if (splits > K / 256) splits = K / 256;
+    return splits < 2 ? 0 : splits;
+}
+
+size_t srx_gemm_workspace_bytes(int M, int N, int K, int batch) {
+    if (batch != 1 || M <= 0 || N <= 0 || K <= 0) return 0;
+    const long a = gemm_tile_splits(M, N, K), b = gemm_skinny_nn_splits(M, N, K);
+    return (size_t)(a > b ? a : b) * M * N * sizeof(float);
 }
 
 int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* ws, size_t ws_bytes,
@@ -643,8 +763,40 @@ int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float
     g.alpha = d->alpha; g.act = d->act; g.accumulate = d->accumulate;
     g.splits = 1; g.ksplit = (d->K + 3) / 4 * 4;
     const size_t need = srx_gemm_workspace_bytes(d->M, d->N, d->K, d->batch);
-    if (need && ws && ws_bytes >= need && al16(ws)) {
-        g.splits = (int)(need / ((size_t)d->M * d->N * sizeof(float)));
+    const bool have_ws = need && ws && ws_bytes >= need && al16(ws);
+    const bool rows_a = d->a_col_stride == 1 || d->M == 1;
+    // skinny routes (M <= 16, one matrix): forward of a dense layer ...
+    const long nn_splits = d->batch == 1 ? gemm_skinny_nn_splits(d->M, d->N, d->K) : 0;
+    if (nn_splits && have_ws && d->b_col_stride == 1 && (d->b_row_stride & 3) == 0 && al16(B)) {
+        g.splits = (int)nn_splits;
+        g.ksplit = (int)(((d->K + nn_splits - 1) / nn_splits + 15) / 16 * 16);
+        g.part = (float*)ws;
+        const int mt = d->M <= 4 ? 4 : (d->M <= 8 ? 8 : 16);
+        const dim3 grid((unsigned)((d->N + 1023) / 1024), (unsigned)g.splits);
+        const size_t lds = (size_t)mt * g.ksplit * sizeof(float);
+        if (mt == 4) hipLaunchKernelGGL(gemm_skinny_nn_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, g);
+        else if (mt == 8) hipLaunchKernelGGL(gemm_skinny_nn_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(gemm_skinny_nn_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(ew_blocks((size_t)d->M * d->N)), dim3(256), 0, (hipStream_t)stream, g);
+        SRX_LAUNCHED("gemm");
+    }
+    // ... and its data gradient: the rows of B are the contiguous ones
+    if (d->batch == 1 && d->M <= 16 && d->N >= 2048 && d->b_row_stride == 1 && (d->b_col_stride & 3) == 0 && al16(B) && rows_a &&
+        (d->K & 255) == 0 && !bias && d->act == SRX_ACT_NONE) {
+        const int mt = d->M <= 4 ? 4 : (d->M <= 8 ? 8 : 16);
+        const size_t lds = (size_t)mt * d->K * sizeof(float);
+        if (lds <= 48 * 1024) {
+            const long trips = ((long)d->N + 16 / mt - 1) / (16 / mt);
+            const unsigned grid = (unsigned)(trips < 4096 ? (trips + 3) / 4 : 1024);
+            if (mt == 4) hipLaunchKernelGGL(gemm_skinny_nt_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+            else if (mt == 8) hipLaunchKernelGGL(gemm_skinny_nt_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL(gemm_skinny_nt_kernel<16>, dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+            SRX_LAUNCHED("gemm");
+        }
+    }
+    const long tile_splits = d->batch == 1 ? gemm_tile_splits(d->M, d->N, d->K) : 0;
+    if (tile_splits && have_ws) {
+        g.splits = (int)tile_splits;
         g.ksplit = ((d->K + g.splits - 1) / g.splits + 15) / 16 * 16;
         g.part = (float*)ws;
     }

@@ -94,7 +94,11 @@ def test_normalize_logloss_preprocess_addscaled_colsum():
     close(ops.column_sums(dev(m)), m.astype(np.float64).sum(axis=0))
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 1024, 8192), (5, 7, 3), (64, 64, 256), (130, 70, 33), (1, 1, 1024), (64, 8192, 1024)])
+@pytest.mark.parametrize('M,N,K', [(64, 1024, 8192), (5, 7, 3), (64, 64, 256), (130, 70, 33), (1, 1, 1024), (64, 8192, 1024),
+                                   # skinny routes (round 3; the discriminator's dense layer at 512 x 512 inputs): M <= 16 against a long K
+                                   # (gemm_skinny_nn_kernel, split-K) and, transposed, against many rows of B (gemm_skinny_nt_kernel)
+                                   (4, 1024, 8192), (8, 4096, 1024), (3, 2052, 512), (16, 1024, 4096), (13, 2500, 768), (2, 260, 4100),
+                                   (1, 2048, 4096)])
 def test_gemm_against_float64(M, N, K):
     from ml_super_resolution_amd import ops
     rng = np.random.default_rng(M + N + K)
@@ -110,6 +114,9 @@ def test_gemm_against_float64(M, N, K):
     out = dev(c0)
     ops.gemm(dev(A), dev(B), out=out, accumulate=True)
     close(out, ref + c0)
+    out = dev(c0)
+    ops.gemm(dev(A), dev(B.T.copy()), trans_b=True, alpha=0.5, out=out, accumulate=True)
+    close(out, 0.5 * ref + c0)
     # deterministic (split-K partials are added in a fixed order)
     assert torch.equal(ops.gemm(dev(A), dev(B)), ops.gemm(dev(A), dev(B)))
 
