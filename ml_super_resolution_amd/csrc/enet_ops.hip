@@ -565,12 +565,31 @@ __global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(const GemmArgs g) {
     }
 }
 
+// Adds the split-K partials in a fixed order and applies the epilogue.  A workgroup owns 64 consecutive elements of C; its
+// four waves each add a quarter of the splits (eight independent running sums: 512 splits of the skinny forward are
+// 16 rounds of loads per thread, not 512), wave 0 adds the four quarter sums.
 __global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const GemmArgs g) {
+    __shared__ float quarter[3][64];
     const size_t total = (size_t)g.M * g.N;
-    SRX_GRID_STRIDE(i, total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const int per = (g.splits + 3) / 4, s0 = wave * per, s1 = (s0 + per < g.splits) ? s0 + per : g.splits;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (i < total) {
+        int sp = s0;
+        for (; sp + 8 <= s1; sp += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += g.part[(size_t)(sp + u) * total + i];
+        for (; sp < s1; ++sp) acc[0] += g.part[(size_t)sp * total + i];
+    }
+    const float mine = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    if (wave) quarter[wave - 1][lane] = mine;
+    __syncthreads();
+    if (wave == 0 && i < total) {
+        const float s = (mine + quarter[0][lane]) + (quarter[1][lane] + quarter[2][lane]);
         const int mm = (int)(i / g.N), n = (int)(i % g.N);
-        float s = 0.f;
-        for (int sp = 0; sp < g.splits; ++sp) s += g.part[(size_t)sp * total + i];
         float* c = g.C + (long)mm * g.scm + (long)n * g.scn;
         float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
         v = gemm_act(v, g.act);
@@ -777,7 +796,7 @@ int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float
         if (mt == 4) hipLaunchKernelGGL(gemm_skinny_nn_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, g);
         else if (mt == 8) hipLaunchKernelGGL(gemm_skinny_nn_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL(gemm_skinny_nn_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, g);
-        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(ew_blocks((size_t)d->M * d->N)), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)(((size_t)d->M * d->N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, g);
         SRX_LAUNCHED("gemm");
     }
     // ... and its data gradient: the rows of B are the contiguous ones
@@ -813,7 +832,7 @@ int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float
     }
     hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles, (unsigned)g.splits, (unsigned)d->batch), dim3(256), 0, (hipStream_t)stream, g);
     if (g.splits > 1)
-        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(ew_blocks((size_t)d->M * d->N)), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)(((size_t)d->M * d->N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, g);
     SRX_LAUNCHED("gemm");
 }
 
