@@ -26,8 +26,9 @@ struct PixWalk {
         n = (int)(t / (unsigned)OH);
         oh = (int)(t - (unsigned)n * (unsigned)OH);
     }
-    __device__ __forceinline__ void step16(int OH, int OW) {
-        ow += 16;
+    __device__ __forceinline__ void step16(int OH, int OW) { step(16, OH, OW); }
+    __device__ __forceinline__ void step(int d, int OH, int OW) {
+        ow += d;
         while (ow >= OW) {          // (at most once per step unless the image is narrower than 16 pixels)
             ow -= OW;
             oh += 1;
@@ -121,14 +122,16 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const ConvArgs a, long
 // then adds its 16 lane groups (xor-shuffles inside a wave, LDS across the four waves) and writes one partial
 // filter in the layout reduce_partials_kernel sums: HWIO gradient, then the bias gradient.
 // NOUT = true: Cin 64, Cout 3 (x is the wide tensor); false: Cin 3, Cout 64 (dpre is the wide tensor).
-template <int KH, int KW, bool NOUT>
+template <int KH, int KW, bool NOUT, int CW = 64>
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, long total_px, int iters) {
-    constexpr int TAPS = KH * KW, CW = 64, CN = 3;
+    constexpr int TAPS = KH * KW, CN = 3;
+    constexpr int LPP = CW / 4;                    // lanes per position (16, or 8 for the 32-channel side), four channels each
+    constexpr int PPI = 256 / LPP;                 // positions per workgroup iteration
     constexpr int NB = NOUT ? CN : 4;              // bias-gradient values per lane
     constexpr int NV = TAPS * 4 * CN + NB;         // values per lane
-    __shared__ float red[4 * NV * 16];
-    const int c4 = threadIdx.x & 15;
-    const int sub = threadIdx.x >> 4;
+    __shared__ float red[4 * NV * LPP];
+    const int c4 = threadIdx.x & (LPP - 1);
+    const int sub = threadIdx.x / LPP;
     const int wave = threadIdx.x >> 6;
     float acc[NV];
 #pragma unroll
@@ -137,11 +140,11 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, lo
         const_cast<float*>(a.x), 0, a.N * a.H * a.W * (NOUT ? CW : CN) * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.dpre), 0, a.N * a.OH * a.OW * (NOUT ? CN : CW) * 4, 0x00020000);
-    const unsigned p0 = blockIdx.x * (unsigned)iters * 16u + sub;
+    const unsigned p0 = blockIdx.x * (unsigned)iters * (unsigned)PPI + sub;
     PixWalk q;
     q.init(p0 < (unsigned)total_px ? p0 : 0u, a.OH, a.OW);
-    for (int it = 0; it < iters; ++it, q.step16(a.OH, a.OW)) {
-        const unsigned p = p0 + (unsigned)it * 16u;
+    for (int it = 0; it < iters; ++it, q.step(PPI, a.OH, a.OW)) {
+        const unsigned p = p0 + (unsigned)it * (unsigned)PPI;
         const bool live = p < (unsigned)total_px;
         int off[TAPS];
         tap_offsets<KH, KW>(off, q, live, a.H, a.W, a.pad_t, a.pad_l, (NOUT ? CW : CN) * 4, NOUT ? 16 * c4 : 0);
@@ -176,21 +179,21 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, lo
             for (int e = 0; e < 4; ++e) acc[TAPS * 4 * CN + e] += d[e];
         }
     }
-    // the wave's four lane groups, then the four waves
+    // the wave's 64 / LPP lane groups, then the four waves
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float r = acc[i];
-        r += __shfl_xor(r, 16);
-        r += __shfl_xor(r, 32);
-        if (sub % 4 == 0) red[(wave * NV + i) * 16 + c4] = r;
+#pragma unroll
+        for (int o = LPP; o < 64; o <<= 1) r += __shfl_xor(r, o);
+        if (sub % (64 / LPP) == 0) red[(wave * NV + i) * LPP + c4] = r;
     }
     __syncthreads();
     float* part = a.part + (size_t)blockIdx.x * a.part_stride;
     const int wn = TAPS * CW * CN;
-    for (int q = threadIdx.x; q < NV * 16; q += 256) {
-        const int i = q >> 4, l = q & 15;
-        const float r = (red[(0 * NV + i) * 16 + l] + red[(1 * NV + i) * 16 + l]) +
-                        (red[(2 * NV + i) * 16 + l] + red[(3 * NV + i) * 16 + l]);
+    for (int q = threadIdx.x; q < NV * LPP; q += 256) {
+        const int i = q / LPP, l = q % LPP;
+        const float r = (red[(0 * NV + i) * LPP + l] + red[(1 * NV + i) * LPP + l]) +
+                        (red[(2 * NV + i) * LPP + l] + red[(3 * NV + i) * LPP + l]);
         if (i < TAPS * 4 * CN) {
             int idx;
             if constexpr (NOUT) {                  // i = (tap * 4 + e) * 3 + c  ->  dW[tap][4l + e][c]
@@ -214,16 +217,21 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradArgs a, lo
 
 bool launch_wgrad_narrow(const ConvKey& k, const WgradArgs& a, int grid, hipStream_t s, hipError_t* err) {
     if (k.kh != 3 || k.kw != 3) return false;
-    const bool nout = a.Cin == 64 && a.Cout == 3, nin = a.Cin == 3 && a.Cout == 64;
-    if (!nout && !nin) return false;
+    // 64 -> 3 (output layers), 3 -> 64 (input layers), 3 -> 32 (the first layer of EnhanceNet's discriminator: on the
+    // cursor MFMA kernel its filter gradient took 470 us at 128 x 128 x 128 -- 4.5 % of a discriminator run)
+    const bool nout = a.Cin == 64 && a.Cout == 3, nin = a.Cin == 3 && a.Cout == 64, nin32 = a.Cin == 3 && a.Cout == 32;
+    if (!nout && !nin && !nin32) return false;
     const long total = (long)a.N * a.OH * a.OW;
     if (total >= (1L << 31) - 4096 || (long)a.N * a.H * a.W * 64 * 4 >= (1L << 31) - 4096 || total * 64 * 4 >= (1L << 31) - 4096)
         return false;
-    const int iters = (int)((total + 16L * grid - 1) / (16L * grid));
+    const long ppi = nin32 ? 32 : 16;          // positions per workgroup iteration
+    const int iters = (int)((total + ppi * grid - 1) / (ppi * grid));
     if (nout)
         hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3, true>), dim3(grid), dim3(256), 0, s, a, total, iters);
-    else
+    else if (nin)
         hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3, false>), dim3(grid), dim3(256), 0, s, a, total, iters);
+    else
+        hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3, false, 32>), dim3(grid), dim3(256), 0, s, a, total, iters);
     *err = hipGetLastError();
     return true;
 }

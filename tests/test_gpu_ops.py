@@ -125,6 +125,11 @@ SHAPES = [
     (3, 6, 9, 3, 3, 64, 'VALID', 'relu'),
     (40, 41, 41, 3, 3, 64, 'SAME', 'relu'),
     (40, 41, 41, 3, 64, 3, 'SAME', None),
+    # the first layer of EnhanceNet's discriminator (3 -> 32): its filter gradient runs wgrad_narrow_kernel<.., 32> (8 lanes per
+    # position, 32 positions per workgroup iteration), incl. images narrower than one iteration and a ragged last iteration
+    (6, 37, 29, 3, 3, 32, 'SAME', 'lrelu'),
+    (3, 9, 5, 3, 3, 32, 'SAME', 'lrelu'),
+    (2, 64, 64, 3, 3, 32, 'VALID', None),
 ]
 
 
