@@ -44,7 +44,9 @@ class EspcnModel(object):
         self._graphs = {}
         # one launch for the whole net while the problem is latency-bound (SRX_ESPCN_FUSED=0: never)
         self.use_single_launch = os.environ.get('SRX_ESPCN_FUSED', '1') != '0'
-        self.single_launch_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_MAX_PIXELS', '20000'))
+        # (measured, round 3, one launch against the three-launch graph: 27 / 52 / 52 us against 69 / 63 / 66 us at 16 k / 28 k /
+        # 37 k LR pixels, level at 46-58 k, behind from 65 k on -- the one-launch kernel's time steps with its rounds of tiles)
+        self.single_launch_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_MAX_PIXELS', '45000'))
         self.inference_path = ('<= %d LR pixels: ONE launch, the three layers chained through LDS per 9x9 tile with the '
                                'sub-pixel store (srx_espcn_forward); larger: f1, f2, f3 with the sub-pixel store fused into '
                                "f3's epilogue, 3 launches%s" % (self.single_launch_max_pixels,
