@@ -307,14 +307,22 @@ void subpixel_pipe_kernel(const float* __restrict__ in, float* __restrict__ out,
         spk[k][1] = (unsigned)(t[2] * 4) | ((unsigned)(t[3] * 4) << 16);
     }
     const int store_off = lane_off - 16 * shift;
-    // LDS float4 slot of the last load slot: inside the chunk, or this thread's dummy slot
+    // LDS float4 slots of the last TWO load slots: inside the chunk, or this thread's dummy slot.  KMAX counts STORE
+    // slots, i.e. it includes the up-to-7-float4 shift: c4 > 256 (KMAX - 1) - 7 only, so when c4 % 256 is 250..255 the
+    // slot before the last also has lanes past the chunk -- written unguarded they would land in the first float4s of
+    // the OTHER buffer, which slower waves may still be gathering from (round-3 advisor finding; every slot below
+    // KMAX - 2 lies inside the chunk: 256 (KMAX - 2) <= c4).
     const int last_i = (KMAX - 1) * 256 + threadIdx.x;
     const bool last_in = last_i < c4;
+    const int prev_i = (KMAX >= 2 ? KMAX - 2 : 0) * 256 + threadIdx.x;
+    const bool prev_in = prev_i < c4;
     auto step = [&](u32x4v (&reg)[KMAX], int p, int cur) {
         float* buf = lds + p * chunk_floats;
         u32x4v* buf4 = reinterpret_cast<u32x4v*>(buf);
 #pragma unroll
-        for (int k = 0; k < KMAX - 1; ++k) buf4[k * 256 + threadIdx.x] = reg[k];
+        for (int k = 0; k < KMAX - 2; ++k) buf4[k * 256 + threadIdx.x] = reg[k];
+        if constexpr (KMAX >= 2)
+            reinterpret_cast<u32x4v*>(lds)[prev_in ? p * c4 + prev_i : 2 * c4 + threadIdx.x] = reg[KMAX - 2];
         reinterpret_cast<u32x4v*>(lds)[last_in ? p * c4 + last_i : 2 * c4 + threadIdx.x] = reg[KMAX - 1];
         issue(reg, cur + DEPTH * G, true);
         lds_barrier();
@@ -680,7 +688,7 @@ hipError_t launch_subpixel(const float* in, float* out, int N, int H, int W, int
             if (e != hipSuccess) return e;
         } else if (nfull) {
             int grid = (int)(nfull < cap ? nfull : cap);
-            if ((size_t)grid < nfull) grid -= grid % 8;   // every chunk of a workgroup starts at the same offset into a 128-byte line
+            if ((size_t)grid < nfull && grid >= 8) grid -= grid % 8;   // every chunk of a workgroup starts at the same offset into a 128-byte line (a cap below 8 keeps its grid: the shift is computed from the first chunk and only costs alignment)
 #define SRX_SUBPIXEL_PIPE(K) case K: launch_subpixel_pipe<K>(depth, kn.throttle, grid, pipe_lds, s, in, out, (int)nfull, chunk, geo); break;
             // chunks of loads in flight per workgroup
             const int per_wg = (int)((nfull + grid - 1) / grid);

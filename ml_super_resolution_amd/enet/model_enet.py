@@ -459,6 +459,7 @@ class EnetModel(object):
         power accumulators `beta1_power`, `beta2_power` (g_trainer, created first) and `beta1_power_1`,
         `beta2_power_1` (d_trainer): beta ** (steps + 1), as in engine.ConvStack.tf_checkpoint_tensors.  (Slot and
         accumulator names as TensorFlow 1.8 is remembered to create them; no TensorFlow-written file to check against.)"""
+        from .. import tf_bundle
         out = {'global_step': np.asarray(self.global_step, dtype=np.int64)}
         for name, val, m, v, to_tf, _ in self._named_buffers():
             out[name] = to_tf(val).detach().cpu().numpy()
@@ -466,11 +467,11 @@ class EnetModel(object):
                 out[name + '/Adam'] = to_tf(m).detach().cpu().numpy()
                 out[name + '/Adam_1'] = to_tf(v).detach().cpu().numpy()
         if self.g_state:
-            out['beta1_power'] = np.asarray(0.9 ** (self.g_state['t'] + 1), dtype=np.float32)
-            out['beta2_power'] = np.asarray(0.999 ** (self.g_state['t'] + 1), dtype=np.float32)
+            out['beta1_power'] = tf_bundle.tf_beta_power(0.9, self.g_state['t'])
+            out['beta2_power'] = tf_bundle.tf_beta_power(0.999, self.g_state['t'])
         if self.discriminator is not None and self.discriminator.pool.opt_m is not None:
-            out['beta1_power_1'] = np.asarray(0.9 ** (self.discriminator.pool.t + 1), dtype=np.float32)
-            out['beta2_power_1'] = np.asarray(0.999 ** (self.discriminator.pool.t + 1), dtype=np.float32)
+            out['beta1_power_1'] = tf_bundle.tf_beta_power(0.9, self.discriminator.pool.t)
+            out['beta2_power_1'] = tf_bundle.tf_beta_power(0.999, self.discriminator.pool.t)
             # not a TensorFlow variable (a Saver restoring by name ignores it): the count the powers stand for
             out['srx/d_trainer_steps'] = np.asarray(self.discriminator.pool.t, dtype=np.int64)
         return out
@@ -482,16 +483,23 @@ class EnetModel(object):
 
     @staticmethod
     def _d_steps_from_checkpoint(values, global_step):
-        """Adam step count of d_trainer.  In order: the explicit count this package writes beside the TensorFlow
-        variables; beta2_power_1 = 0.999 ** (t + 1), which stays a normal float32 for ~87,000 steps (float32 rounding
-        moves the recovered count by < 1e-4 of a step); the schedule of the training script (d_trainer on every third
-        step, experiment_train.py:112).  beta1_power_1 = 0.9 ** (t + 1) underflows after ~960 steps and is never used."""
+        """Adam step count of d_trainer.  In order: (1) the explicit count this package writes beside the TensorFlow
+        variables; (2) the schedule of the training script -- d_trainer runs on every third step
+        (enet/enet/experiment_train.py:112), so a checkpoint the reference wrote at `global_step` has seen exactly
+        (global_step + 2) // 3 of them; (3) only if beta2_power_1 contradicts that schedule (a checkpoint trained under
+        another one): the inverse of beta2_power_1 = prod of (t + 1) float32 multiplications by float32(0.999) =
+        0.99900001287..., which stays a normal float32 for ~87,000 steps.  TensorFlow's repeated float32 rounding makes
+        that inverse drift by about 1.3e-5 * t steps (off by one from t ~ 40,000 on), hence only the fallback.
+        beta1_power_1 = 0.9 ** (t + 1) underflows after ~960 steps and is never used."""
         if 'srx/d_trainer_steps' in values:
             return int(values['srx/d_trainer_steps'])
+        sched = (int(global_step) + 2) // 3
         b2p = float(values['beta2_power_1']) if 'beta2_power_1' in values else 0.0
         if np.isfinite(b2p) and 1.2e-38 < b2p < 1.0:
-            return max(int(round(np.log(b2p) / np.log(0.999))) - 1, 0)
-        return (int(global_step) + 2) // 3
+            t2 = max(int(round(np.log(b2p) / np.log(float(np.float32(0.999))))) - 1, 0)
+            if abs(t2 - sched) > max(2, int(1e-4 * sched)):
+                return t2
+        return sched
 
     def load_tf_checkpoint(self, prefix):
         """Restores the g_ / d_ variables, global_step and (when present) both optimizers' state."""

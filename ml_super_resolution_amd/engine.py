@@ -304,8 +304,16 @@ class ConvStack(object):
         reference graph ({name: array}; VDSR's non-trainable `learning_rate`, vdsr/vdsr/model_vdsr.py:136-141 --
         Saver().restore needs every global variable to be present).
         beta powers: TF-1.x AdamOptimizer creates them with the value beta and multiplies them by beta once per
-        apply (_finish), so after N steps the checkpoint holds beta ** (N + 1).  (From the TF 1.8 optimizer as
-        remembered: the source is not available here, and no TF-written checkpoint exists to check against.)"""
+        apply (_finish), so after N steps the checkpoint holds float32(beta) ** (N + 1) (tf_bundle.tf_beta_power).
+        UNVERIFIED CONVENTIONS -- TensorFlow's source is not available here and no TF-written checkpoint exists to
+        check against; a maintainer holding a real `model.ckpt-25600` should check, in
+        this order: (1) the key set of its `.index` (tf_bundle.list_variables) against this function's: the non-slot
+        accumulators are expected at top level as `beta1_power` / `beta2_power` (a second optimizer in the same graph:
+        `beta1_power_1` / `beta2_power_1`), the slots as `<var>/Adam` (m) and `<var>/Adam_1` (v), Momentum's as
+        `<var>/Momentum`; (2) that `beta1_power` equals 0.9 ** (global_step + 1) and not ** global_step; (3) that the
+        layer scopes are `conv2d`, `conv2d_1`, ... in creation order (tf.layers' auto-numbering) for VDSR and
+        `f1` / `f2` / `f3` for ESPCN; (4) dtype / shape of `global_step` (int64 scalar expected).  The container format
+        itself (table blocks, CRCs, BundleEntryProto fields) is checked against published known-answer vectors only."""
         import numpy as np
         out = {k: v.detach().cpu().numpy() for k, v in self.variables().items()}
         out['global_step'] = np.asarray(self.global_step, dtype=np.int64)
@@ -320,8 +328,9 @@ class ConvStack(object):
                     if two:
                         out['%s/%s/Adam_1' % (scope, kind)] = view(i, self.opt_v).detach().cpu().numpy()
             if two:
-                out['beta1_power'] = np.asarray(adam_betas[0] ** (self.global_step + 1), dtype=np.float32)
-                out['beta2_power'] = np.asarray(adam_betas[1] ** (self.global_step + 1), dtype=np.float32)
+                from . import tf_bundle
+                out['beta1_power'] = tf_bundle.tf_beta_power(adam_betas[0], self.global_step)
+                out['beta2_power'] = tf_bundle.tf_beta_power(adam_betas[1], self.global_step)
         return out
 
     def save_tf_checkpoint(self, prefix, adam_betas=(0.9, 0.999), extra=None, write_state=True):

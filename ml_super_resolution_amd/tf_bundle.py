@@ -580,9 +580,28 @@ def save_checkpoint(prefix, tensors, num_shards=1, compress_index=False):
     # BundleHeaderProto { num_shards; endianness = LITTLE (0, default: omitted); version { producer = 1 } }
     header = _pb_varint_field(1, num_shards) + _pb_bytes_field(3, _pb_varint_field(1, 1))
     write_table(prefix + '.index.tmp', [(b'', header)] + items, compress=compress_index)
+    # (overwriting an existing prefix: its index goes first, so that a kill between the renames below never leaves the
+    # OLD index over NEW data -- a prefix without an index is simply not a checkpoint, see is_checkpoint_prefix)
+    if os.path.exists(prefix + '.index'):
+        os.remove(prefix + '.index')
     for sh in range(num_shards):
         os.replace(_data_path(prefix, sh, num_shards) + '.tmp', _data_path(prefix, sh, num_shards))
     os.replace(prefix + '.index.tmp', prefix + '.index')
+
+
+def tf_beta_power(beta, steps):
+    """The value of AdamOptimizer's `beta1_power` / `beta2_power` accumulator after `steps` applies, as a float32 scalar:
+    TF-1.x creates it with the value beta and multiplies it by beta (a float32 tensor) once per apply, so the checkpoint
+    holds float32(beta) ** (steps + 1) up to the random walk of the float32 roundings (~6e-8 * sqrt(steps) relative).
+    The base is float32(beta), not the Python float: float32(0.999) = 0.99900001287..., and over 40,000 steps the two
+    differ by a whole step's factor."""
+    return np.asarray(float(np.float32(beta)) ** (int(steps) + 1), dtype=np.float32)
+
+
+# Prefixes THIS process has saved, per directory: the only ones update_checkpoint_state may delete.  tf.train.Saver keeps
+# the same kind of list per Saver instance (`_last_checkpoints`) -- checkpoints it finds listed in the state file of a
+# directory it resumes in (an earlier run's, TensorFlow's own) stay listed and stay on disk.
+_saved_by_this_process = {}
 
 
 def update_checkpoint_state(prefix, max_to_keep=5):
@@ -590,8 +609,10 @@ def update_checkpoint_state(prefix, max_to_keep=5):
     tf.train.latest_checkpoint(dir) reads (vdsr/vdsr/experiment_train.py:108): the newest prefix as
     `model_checkpoint_path`, the known prefixes under `all_model_checkpoint_paths` (paths relative to the
     directory, as the Saver writes them).  Like tf.train.Saver(max_to_keep=5) -- the default every script of the
-    reference uses -- at most `max_to_keep` prefixes stay listed and the files of the ones that drop off the list are
-    deleted.  The state file itself is replaced atomically."""
+    reference uses -- at most `max_to_keep` of the prefixes THIS PROCESS saved stay on disk: the older ones of them are
+    deleted and dropped from the list.  Entries the state file already held (an earlier run's checkpoints, TensorFlow's
+    own, absolute paths elsewhere) are never deleted; they stay listed in front, as long as they exist.  The state file
+    itself is replaced atomically."""
     d = os.path.dirname(os.path.abspath(prefix))
     name = os.path.basename(prefix)
     state = os.path.join(d, 'checkpoint')
@@ -601,16 +622,22 @@ def update_checkpoint_state(prefix, max_to_keep=5):
             line = line.strip()
             if line.startswith('all_model_checkpoint_paths:'):
                 known.append(line.split(':', 1)[1].strip().strip('"'))
-    known = [k for k in known if k != name] + [name]
-    dropped = known[:-max_to_keep] if max_to_keep and len(known) > max_to_keep else []
-    known = known[len(dropped):]
+    mine = _saved_by_this_process.setdefault(d, [])
+    if name in mine:
+        mine.remove(name)
+    mine.append(name)
+    dropped = mine[:-max_to_keep] if max_to_keep and len(mine) > max_to_keep else []
+    del mine[:len(dropped)]
+    foreign = [k for k in known if k not in mine and k not in dropped and k != name and
+               is_checkpoint_prefix(k if os.path.isabs(k) else os.path.join(d, k))]
+    known = foreign + mine
     with open(state + '.tmp', 'w') as f:
         f.write('model_checkpoint_path: "%s"\n' % name)
         for k in known:
             f.write('all_model_checkpoint_paths: "%s"\n' % k)
     os.replace(state + '.tmp', state)
     for k in dropped:
-        old = k if os.path.isabs(k) else os.path.join(d, k)
+        old = os.path.join(d, k)         # (names this process wrote into this directory: never absolute, never foreign)
         for path in [old + '.index'] + glob.glob(glob.escape(old) + '.data-?????-of-?????'):
             if os.path.exists(path):
                 os.remove(path)

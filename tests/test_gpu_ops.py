@@ -223,6 +223,30 @@ def test_subpixel_random_shapes_every_kernel_route(ops):
         assert torch.equal(back.view(torch.int32), t.view(torch.int32)), (n, h, w, c, r)
 
 
+def test_subpixel_pipe_kernel_chunk_boundary_slots(ops):
+    """subpixel_pipe_kernel with several trips per workgroup and a chunk whose float4 count is within 6 of a multiple of
+    256 (or exactly one): the load slot BEFORE the last then has lanes past the chunk too, and until round 4 those lanes
+    wrote their out-of-range zeros into the first float4s of the other LDS buffer while slower waves could still be
+    gathering from it (round-3 advisor finding, derived statically; c4 % 256 in 250..255).  [8,340,340,12] r=2 is the
+    advisor's example (c4 = 1020, 2,720 chunks, 3 trips); the others walk c4 % 256 over 250..255 and 0.  Both directions,
+    bit-exact against the oracle's index map on a strided sample, and the round trip on the whole tensor."""
+    rng = np.random.default_rng(404)
+    shapes = [(8, 340, 340, 3, 2)] + [(5, 1000, w, 1, 2) for w in (1018, 1019, 1020, 1021, 1022, 1023, 1024)]
+    for (n, h, w, c, r) in shapes:
+        g = torch.Generator(device='cuda').manual_seed(w)
+        t = torch.randint(-(1 << 31), (1 << 31) - 1, (n, h, w, c * r * r), dtype=torch.int64, device='cuda', generator=g)
+        t = t.to(torch.int32).view(torch.float32)
+        for rep in range(3):     # (the race was timing-dependent)
+            d = ops.depth_to_space(t, r)
+            back = ops.space_to_depth(d, r)
+            assert torch.equal(back.view(torch.int32), t.view(torch.int32)), (n, h, w, c, r, rep)
+        step = 97
+        bits = t[:, ::step].contiguous().view(torch.int32).cpu().numpy().view(np.uint32)
+        got = d.view(n, h, r, w * r, c)[:, ::step].contiguous().view(n, -1, w * r, c)
+        np.testing.assert_array_equal(got.view(torch.int32).cpu().numpy().view(np.uint32), O.depth_to_space(bits, r), err_msg=str((n, h, w, c, r)))
+        del t, d, back, got
+
+
 def test_subpixel_buffers_aligned_to_16_bytes_only(ops):
     """The pipelined kernel shifts its output-side lane assignment so that every store instruction starts on a 128-byte
     line; the shift comes from the ACTUAL address of each chunk.  Input and output placed 16, 32, 80 bytes off a line

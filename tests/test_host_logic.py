@@ -169,6 +169,7 @@ def test_enet_resume_step_counts_survive_beta_power_underflow(tmp_path, g_steps)
     third = _small_enet(seed=6)
     third.load_tf_checkpoint(prefix2)
     assert third.g_state['t'] == g_steps
+    # (P.t is 5 off the schedule: beta2_power_1 contradicts it and wins while it is a normal float32)
     if 0.999 ** (P.t + 1) > 1.2e-38:
         assert third.discriminator.pool.t == P.t
     else:
@@ -178,8 +179,22 @@ def test_enet_resume_step_counts_survive_beta_power_underflow(tmp_path, g_steps)
 def test_enet_d_steps_guards():
     from ml_super_resolution_amd.enet.model_enet import EnetModel
     f = EnetModel._d_steps_from_checkpoint
+
+    def tf_accumulator(t):
+        # what TensorFlow holds after t applies: created as float32(0.999), multiplied by float32(0.999) t times, in float32
+        b, p = np.float32(0.999), np.float32(0.999)
+        for _ in range(t):
+            p = np.float32(p * b)
+        return p
     for t in (0, 1, 333, 1667, 20000, 80000):
-        assert f({'beta2_power_1': np.float32(0.999 ** (t + 1))}, 0) == t
+        # a schedule that does not fit (it would give t + 10): the accumulator decides, and float32's base is the one inverted
+        assert f({'beta2_power_1': tf_accumulator(t)}, 3 * (t + 10) - 2) == t
+    # a checkpoint the reference wrote: d_trainer ran on steps 0, 3, 6, ... -> the schedule's count, exactly, whatever the
+    # accumulator's float32 drift (round-3 advisor: log(0.999) instead of log(float32(0.999)) is off by one from ~40k steps)
+    for g in (999, 29999, 119999, 299999):
+        t = (g + 2) // 3
+        assert f({'beta2_power_1': np.float32(0.999 ** (t + 1))}, g) == t
+        assert f({'beta2_power_1': np.float32(float(np.float32(0.999)) ** (t + 1))}, g) == t
     for bad in (np.float32(0.0), np.float32(1e-42), np.float32('nan'), np.float32(1.0)):
         assert f({'beta2_power_1': bad, 'beta1_power_1': np.float32(0.0)}, 2999) == 1000
     assert f({}, 10) == 4

@@ -277,3 +277,50 @@ def test_saver_housekeeping_atomic_writes_max_to_keep_and_scan_fallback(tmp_path
     assert B.latest_checkpoint(str(d), scan=True) == str(d / 'model.ckpt-7999')
     assert int(B.load_checkpoint(B.latest_checkpoint(str(d), scan=True))['global_step']) == 7999
     assert B.newest_bundle(str(tmp_path / 'nothing')) is None
+
+
+def test_saver_housekeeping_never_deletes_checkpoints_it_did_not_write(tmp_path):
+    """tf.train.Saver only deletes checkpoints the same Saver instance wrote.  A directory that already holds checkpoints
+    (an earlier run's, TensorFlow's own -- listed in the state file, possibly by absolute path) is resumed in and saved
+    to more than max_to_keep times: the older files stay on disk and stay listed (round-3 advisor finding)."""
+    from ml_super_resolution_amd import tf_bundle as B
+    d = tmp_path / 'ckpt'
+    d.mkdir()
+    elsewhere = tmp_path / 'elsewhere'
+    elsewhere.mkdir()
+    t = {'w': np.zeros((2,), np.float32)}
+    for n in (100, 200, 300):
+        B.save_checkpoint(str(d / ('model.ckpt-%d' % n)), t)
+    B.save_checkpoint(str(elsewhere / 'model.ckpt-7'), t)
+    open(str(d / 'checkpoint'), 'w').write(
+        'model_checkpoint_path: "model.ckpt-300"\n' + 'all_model_checkpoint_paths: "%s"\n' % str(elsewhere / 'model.ckpt-7') +
+        ''.join('all_model_checkpoint_paths: "model.ckpt-%d"\n' % n for n in (100, 200, 300)) +
+        'all_model_checkpoint_paths: "model.ckpt-gone"\n')
+    B._saved_by_this_process.pop(str(d), None)
+    for n in range(1000, 9000, 1000):
+        prefix = str(d / ('model.ckpt-%d' % n))
+        B.save_checkpoint(prefix, t)
+        B.update_checkpoint_state(prefix)
+    for n in (100, 200, 300):
+        assert B.is_checkpoint_prefix(str(d / ('model.ckpt-%d' % n)))
+    assert B.is_checkpoint_prefix(str(elsewhere / 'model.ckpt-7'))
+    mine = [4000, 5000, 6000, 7000, 8000]
+    assert sorted(int(n[len('model.ckpt-'):-len('.index')]) for n in os.listdir(str(d)) if n.endswith('.index')) == [100, 200, 300] + mine
+    text = open(str(d / 'checkpoint')).read().splitlines()
+    assert text[0] == 'model_checkpoint_path: "model.ckpt-8000"'
+    assert text[1:] == (['all_model_checkpoint_paths: "%s"' % str(elsewhere / 'model.ckpt-7')] +
+                        ['all_model_checkpoint_paths: "model.ckpt-%d"' % n for n in [100, 200, 300] + mine])   # (the dangling entry is dropped)
+    # overwriting an existing prefix: the result is a complete, readable bundle
+    B.save_checkpoint(str(d / 'model.ckpt-8000'), {'w': np.ones((2,), np.float32)})
+    assert float(B.load_checkpoint(str(d / 'model.ckpt-8000'))['w'][0]) == 1.0
+
+
+def test_tf_beta_power_uses_float32_base():
+    from ml_super_resolution_amd import tf_bundle as B
+    b, p = np.float32(0.999), np.float32(0.999)
+    for _ in range(50000):
+        p = np.float32(p * b)
+    got = B.tf_beta_power(0.999, 50000)
+    assert got.dtype == np.float32 and abs(float(got) / float(p) - 1.0) < 1e-4          # the float32 product's random walk
+    assert abs(0.999 ** 50001 / float(p) - 1.0) > 3e-4                                  # the Python-float base is a step's factor off by now
+    assert float(B.tf_beta_power(0.9, 0)) == float(np.float32(0.9))
