@@ -146,6 +146,85 @@ def cpu_library_baseline(rank):
         return {'value': None, 'error': repr(exc)}
 
 
+def cpu_small_configs(rank):
+    """BASELINE configs[0] ("SRCNN 9-1-5 on one 256x256 image, CPU reference path") and configs[1] (ESPCN 3x inference, batch
+    32 of 17x17 LR patches) timed on this host's cores, as BASELINE.md section 4 promises: the oracle's C restatement
+    (`port`, OpenMP) and torch's CPU convolutions (oneDNN: the optimised-library stand-in for the TensorFlow-Eigen path
+    that cannot run here).  configs[0]'s network input is the 243x243 RGB crop the reference's VALID geometry implies
+    (srcnn/srcnn.py:14-16,28-40: 256 -> 243 -> 231)."""
+    if rank != 0:
+        return {}
+    out = {}
+    try:
+        from oracle import oracle as O
+        import torch.nn.functional as F
+        cores = int(O.clib().srx_ref_set_num_threads(usable_cpus()))
+        torch.set_num_threads(usable_cpus())
+        rng = np.random.default_rng(101)
+
+        def best_ms(fn, budget_s=3.0, min_reps=3, max_reps=40):
+            fn()
+            times, t0 = [], time.perf_counter()
+            while len(times) < min_reps or (time.perf_counter() - t0 < budget_s and len(times) < max_reps):
+                t1 = time.perf_counter()
+                fn()
+                times.append(time.perf_counter() - t1)
+            return round(min(times) * 1e3, 3), len(times)
+
+        # --- configs[0]: relu(conv9x9 3->64) -> relu(conv1x1 64->32) -> tanh(conv5x5 32->3), VALID
+        sp = [(rng.normal(0, 0.05, (9, 9, 3, 64)).astype(np.float32), np.zeros(64, np.float32)),
+              (rng.normal(0, 0.05, (1, 1, 64, 32)).astype(np.float32), np.zeros(32, np.float32)),
+              (rng.normal(0, 0.05, (5, 5, 32, 3)).astype(np.float32), np.zeros(3, np.float32))]
+        img = rng.uniform(-1, 1, (1, 243, 243, 3)).astype(np.float32)
+
+        def srcnn_port():
+            t = O.c_conv2d_fwd(img, sp[0][0], sp[0][1], 'VALID', 'relu')
+            t = O.c_conv2d_fwd(t, sp[1][0], sp[1][1], 'VALID', 'relu')
+            return O.c_conv2d_fwd(t, sp[2][0], sp[2][1], 'VALID', 'tanh')
+        tw = [(torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1))), torch.from_numpy(b)) for w, b in sp]
+        timg = torch.from_numpy(np.ascontiguousarray(img.transpose(0, 3, 1, 2)))
+
+        def srcnn_lib():
+            with torch.no_grad():
+                t = F.relu(F.conv2d(timg, tw[0][0], tw[0][1]))
+                t = F.relu(F.conv2d(t, tw[1][0], tw[1][1]))
+                return torch.tanh(F.conv2d(t, tw[2][0], tw[2][1]))
+        pm, pr = best_ms(srcnn_port)
+        lm, lr_ = best_ms(srcnn_lib)
+        out['srcnn_c1_cpu_ms'] = {'port_ms': pm, 'library_ms': lm, 'cores': cores, 'statistic': 'best of %d / %d repetitions' % (pr, lr_),
+                                  'what': 'SRCNN 9-1-5 VALID forward on one 243x243 RGB image -> 231x231 (BASELINE configs[0]): '
+                                          'oracle/srx_oracle.c (OpenMP) / torch %s CPU conv2d (oneDNN)' % torch.__version__}
+        # --- configs[1]: tanh(conv5x5 3->64) -> tanh(conv3x3 64->32) -> conv3x3 32->27, SAME, then depth-to-space r = 3
+        ep = [(rng.normal(0, 0.05, (5, 5, 3, 64)).astype(np.float32), np.zeros(64, np.float32)),
+              (rng.normal(0, 0.05, (3, 3, 64, 32)).astype(np.float32), np.zeros(32, np.float32)),
+              (rng.normal(0, 0.05, (3, 3, 32, 27)).astype(np.float32), np.zeros(27, np.float32))]
+        lrp = rng.uniform(-1, 1, (32, 17, 17, 3)).astype(np.float32)
+
+        def espcn_port():
+            t = O.c_conv2d_fwd(lrp, ep[0][0], ep[0][1], 'SAME', 'tanh')
+            t = O.c_conv2d_fwd(t, ep[1][0], ep[1][1], 'SAME', 'tanh')
+            return O.c_depth_to_space(O.c_conv2d_fwd(t, ep[2][0], ep[2][1], 'SAME', None), 3)
+        te = [(torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1))), torch.from_numpy(b)) for w, b in ep]
+        # (TensorFlow's channel order (dy, dx, c) is not pixel_shuffle's (c, dy, dx): the filters are permuted once, outside the timing)
+        perm = torch.arange(27).view(3, 3, 3).permute(2, 0, 1).reshape(-1)
+        w3, b3 = te[2][0][perm].contiguous(), te[2][1][perm].contiguous()
+        tlr = torch.from_numpy(np.ascontiguousarray(lrp.transpose(0, 3, 1, 2)))
+
+        def espcn_lib():
+            with torch.no_grad():
+                t = torch.tanh(F.conv2d(tlr, te[0][0], te[0][1], padding=2))
+                t = torch.tanh(F.conv2d(t, te[1][0], te[1][1], padding=1))
+                return F.pixel_shuffle(F.conv2d(t, w3, b3, padding=1), 3)
+        pm, pr = best_ms(espcn_port)
+        lm, lr_ = best_ms(espcn_lib)
+        out['espcn_c2_cpu_ms'] = {'port_ms': pm, 'library_ms': lm, 'cores': cores, 'statistic': 'best of %d / %d repetitions' % (pr, lr_),
+                                  'what': 'ESPCN 3x forward + depth-to-space on 32 LR patches of 17x17 (BASELINE configs[1]): '
+                                          'oracle/srx_oracle.c (OpenMP) / torch %s CPU conv2d + pixel_shuffle (oneDNN)' % torch.__version__}
+    except Exception as exc:     # comparators, not part of the measurement
+        out['small_configs_cpu_error'] = repr(exc)
+    return out
+
+
 TRAFFIC_SOURCES = ('conv_kernels.hip.h', 'launchers.h', 'pipe_inst_k3c64.hip', 'srx_api.hip')
 
 
@@ -201,6 +280,7 @@ def extras(model, dev, stream, x64, y64, px):
                      'what': '3x3 64->64 %s at 256x41x41%s' % (name, ' incl. the reduction of the partial filters and the '
                                                              'regulariser term' if name == 'wgrad' else ' + fused ReluGrad')}
     del dx, ws
+    out['vdsr_recipe_64x128'] = vdsr_recipe(dev, stream)
     # -- sub-pixel map at the north-star bandwidth shape, 8 rotating buffer pairs (744 MB > Infinity Cache)
     pairs = 8
     ins = [torch.rand((256, 41, 41, 27), device=dev) for _ in range(pairs)]
@@ -296,6 +376,49 @@ def extras(model, dev, stream, x64, y64, px):
     except Exception as exc:             # a secondary number must never take the primary line down
         out['enet_pat'] = {'error': repr(exc)}
     return out
+
+
+def vdsr_recipe(dev, stream, batch=64, size=128):
+    """The shape the reference itself trains VDSR-20 at (vdsr/makefile:22-29: --image_size=128 --batch_size=64): rows of
+    128 pixels are too wide for full-width LDS tiles, so the body layers run on 32-column strips (conv_pipe_strip_kernel,
+    wgrad_pipe_strip_kernel).  Train step and the three body-layer kernels, HIP events on the launch stream."""
+    from ml_super_resolution_amd import ops
+    from ml_super_resolution_amd.vdsr import model_vdsr
+    try:
+        m = model_vdsr.VdsrModel(num_layers=20, use_adam=True, device=dev, seed=107)
+        g = torch.Generator(device=dev).manual_seed(108)
+        hd = torch.rand((batch, size, size, 3), device=dev, generator=g) * 2 - 1
+        sd = (hd + 0.1 * torch.randn((batch, size, size, 3), device=dev, generator=g)).clamp(-1, 1)
+        for _ in range(2):
+            m.train_step(sd, hd, 5e-5)
+        ms = hip_event_time_ms(lambda: m.train_step(sd, hd, 5e-5), 5, stream)
+        fwd_ms = hip_event_time_ms(lambda: m.forward(sd), 5, stream)
+        px = batch * size * size
+        tf = TRAIN_FLOP_PER_PX * px / (ms * 1e-3) / 1e12
+        out = {'what': 'VDSR-20 train step at the reference recipe\'s shape (vdsr/makefile:22-29): batch %d of %dx%d, fwd + MSE/L2 + bwd + TF-Adam' % (batch, size, size),
+               'train_ms': round(ms, 3), 'patches_per_s': round(batch / (ms * 1e-3), 1), 'train_tflops': round(tf, 2),
+               'train_frac_of_fp32_mfma_peak': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+               'fwd_ms': round(fwd_ms, 3), 'fwd_hr_mpix_per_s': round(px / (fwd_ms * 1e-3) / 1e6, 2),
+               'fwd_frac_of_fp32_mfma_peak': round(FWD_FLOP_PER_PX * px / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        k, b = m.stack.kernel(5), m.stack.bias(5)
+        del m
+        x = torch.rand((batch, size, size, 64), device=dev) * 2 - 1
+        y = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(k), torch.empty(64, device=dev)
+        ws = torch.empty((ops.bwd_filter_workspace_bytes(x.shape, k.shape) + 3) // 4, device=dev)
+        fns = {'fwd': lambda: ops.conv2d_fwd(x, k, b, 'same', 'relu', out=y),
+               'dgrad': lambda: ops.conv2d_bwd_data(y, k, x.shape, 'same', x_in=x, in_act='relu', out=dx),
+               'wgrad': lambda: ops.conv2d_bwd_filter(x, y, k.shape, 'same', w_for_decay=k, wd_scale=1e-4, dw=dw, dbias=db, workspace=ws)}
+        for name, fn in fns.items():
+            fn()
+            lms = hip_event_time_ms(fn, 10, stream)
+            ltf = MID_LAYER_FLOP_PER_PX * px / (lms * 1e-3) / 1e12
+            out[name] = {'launch_ms': round(lms, 4), 'achieved': round(ltf, 2), 'frac': round(ltf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        out['kernels'] = 'conv_pipe_strip_kernel (fwd, dgrad + ReluGrad), wgrad_pipe_strip_kernel + reduce_partials_kernel: 3x3 64->64 at %dx%dx%d, TFLOP/s of %g peak' % (batch, size, size, PEAK_FP32_MFMA_TFLOPS)
+        return out
+    except Exception as exc:             # a secondary number must never take the primary line down
+        return {'error': repr(exc)}
 
 
 def launch_ranks(n):
@@ -450,6 +573,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rank)
             line['cpu_library_baseline'] = cpu_library_baseline(rank)
+            line.update(cpu_small_configs(rank))
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -90,6 +90,18 @@ const char* srx_last_error(void);
  * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
 int srx_set_conv_path(int pipelined);
 
+/* Selects the filter-gradient (Conv2DBackpropFilter) kernel family:
+ *   2 (default)  3x3 64 -> 64 layers on one workgroup per CU with a double-buffered LDS tile (full-width tiles:
+ *                wgrad_pipe_kernel; images too wide for them: 32-column strips, wgrad_rows_strip_kernel); other
+ *                shapes as path 1;
+ *   1            the linear-walk kernels with two workgroups per CU (wgrad_lin_kernel / wgrad_lin_strip_kernel)
+ *                wherever they apply; other shapes as path 0;
+ *   0            the per-lane cursor kernel (wgrad_mfma_kernel) for every shape;
+ *   < 0          back to the environment's default (SRX_WGRAD_LIN / SRX_WGRAD_PIPE / SRX_WGRAD_PIPE_STRIP).
+ * The paths differ in how a layer's pixels are dealt out to workgroups, i.e. in the order of the fp32 additions:
+ * results agree to rounding.  A tuning / A-B switch.  Returns the old value. */
+int srx_set_wgrad_path(int path);
+
 /* Bytes of caller-owned workspace an op uses.  BWD_FILTER: required (per-workgroup partials).
  * FWD / BWD_DATA: optional 256 bytes holding the tile counter of dynamic scheduling; with ws == NULL
  * those ops fall back to a static work split (same results, a few per cent slower at large sizes). */
@@ -222,6 +234,18 @@ size_t srx_reduce_scratch_bytes(void);
 int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel, float lr,
                      float beta1, float beta2, float eps, int64_t t, float grad_scale,
                      srx_stream_t stream);
+
+/* The same update with the step count and the learning rate in DEVICE memory, so that a whole train step captured as a
+ * HIP graph replays without a per-step kernel argument (ESPCN / SRCNN steps are a dozen launches of ~10 us:
+ * espcn/makefile:30-36 trains 1.6 M of them).  `state` is 32 bytes of 16-byte-aligned device memory owned by the caller:
+ *   { int64 t;      steps applied so far (0 before the first); the kernel uses t + 1 and advances it
+ *     float lr;     the fed learning rate (the caller rewrites it when its schedule changes it)
+ *     float lr_t;   out: the bias-corrected rate the last step used
+ *     uint32 done, pad;   zero-initialised scratch }
+ * lr_t = lr*sqrt(1-b2^(t+1))/(1-b1^(t+1)) is evaluated on the device in double precision, the expression of
+ * srx_adam_tf_step.  Steps on one state block must be ordered on one stream. */
+int srx_adam_tf_step_dev(float* w, const float* g, float* m, float* v, size_t numel, void* state,
+                         float beta1, float beta2, float eps, float grad_scale, srx_stream_t stream);
 
 /* tf.train.MomentumOptimizer(lr, mom) on gradients clipped element-wise to +-cap:
  *   g=clip(g*grad_scale,-cap,cap); acc=mom*acc+g; w-=lr*acc.

@@ -20,10 +20,10 @@ PAD_BY_NAME = {'same': PAD_SAME, 'valid': PAD_VALID}
 
 # every symbol include/srx.h declares
 EXPORTS = [
-    'srx_version', 'srx_last_error', 'srx_set_conv_path', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
+    'srx_version', 'srx_last_error', 'srx_set_conv_path', 'srx_set_wgrad_path', 'srx_conv2d_workspace_bytes', 'srx_conv2d_fwd',
     'srx_conv2d_bwd_data', 'srx_conv2d_bwd_filter', 'srx_conv2d_bwd_filter_partials', 'srx_conv2d_bwd_filter_reduce', 'srx_act_bwd', 'srx_depth_to_space',
     'srx_space_to_depth', 'srx_stream_copy', 'srx_mse_fwd_bwd', 'srx_l2_loss', 'srx_reduce_scratch_bytes',
-    'srx_adam_tf_step', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
+    'srx_adam_tf_step', 'srx_adam_tf_step_dev', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
     'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
     'srx_conv2d_bwd_data_acc', 'srx_conv3x3_blocked', 'srx_conv3x3_blocked_bwd_filter_workspace_bytes', 'srx_conv3x3_blocked_bwd_filter',
     'srx_espcn_forward', 'srx_srcnn_forward', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_maxpool2x2_bwd_masked', 'srx_subsample2', 'srx_subsample2_bwd',
@@ -72,6 +72,7 @@ def lib():
     L.srx_version.restype = ctypes.c_char_p
     L.srx_last_error.restype = ctypes.c_char_p
     L.srx_set_conv_path.argtypes = [i]
+    L.srx_set_wgrad_path.argtypes = [i]
     L.srx_conv2d_workspace_bytes.argtypes = [dp, i]
     L.srx_conv2d_workspace_bytes.restype = sz
     L.srx_reduce_scratch_bytes.restype = sz
@@ -87,6 +88,7 @@ def lib():
     L.srx_mse_fwd_bwd.argtypes = [vp, vp, sz, f, vp, i, vp, vp, vp]
     L.srx_l2_loss.argtypes = [vp, vp, sz, f, vp, i, vp, vp]
     L.srx_adam_tf_step.argtypes = [vp, vp, vp, vp, sz, f, f, f, f, ctypes.c_int64, f, vp]
+    L.srx_adam_tf_step_dev.argtypes = [vp, vp, vp, vp, sz, vp, f, f, f, f, vp]
     L.srx_momentum_clip_step.argtypes = [vp, vp, vp, sz, f, f, f, f, vp]
     L.srx_rownorm_loss_fwd_bwd.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.srx_psnr.argtypes = [vp, vp, vp, i, sz, f, vp]

@@ -2046,6 +2046,31 @@ __device__ __forceinline__ float dpre_fire_tab(__amdgpu_buffer_rsrc_t rsrc, int 
     return b;
 }
 
+// the strip stager's load with an accumulation-register destination (see stage_fire_z)
+__device__ __forceinline__ f32x4 stage_fire_za(unsigned long long m, unsigned long long r, int so, __amdgpu_buffer_rsrc_t rsrc,
+                                               int voff_lane) {
+    f32x4 v;
+    unsigned long long z;
+    const int oob = 0x7ff00000;
+    asm volatile("s_andn2_b64 %1, %6, %5\n\t"
+                 "s_mov_b64 exec, %5\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                 "s_mov_b64 exec, %1\n\tbuffer_load_dwordx4 %0, %2, %3, %7 offen\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&a"(v), "=&s"(z) : "v"(voff_lane), "s"(rsrc), "s"(so), "s"(m), "s"(r), "s"(oob) : "memory", "scc");
+    return v;
+}
+// NT: the dpre stream is read exactly once, by exactly one wave -- marked non-temporal so that it does not push the x
+// tile's halo rows (re-read by the same workgroup one tile later) out of the L2
+template <bool NT>
+__device__ __forceinline__ float dpre_fire_tab_nt(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    float b;
+    if constexpr (NT)
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen nt" : "=&a"(b) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    else
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&a"(b) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return b;
+}
+
 template <int KH, int KW, int CINP, int NCH>
 __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2292,6 +2317,277 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradArgs a) {
     if (a.trace && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
         tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_loop; tr[3] = t_end; tr[4] = t_full;
+    }
+#endif
+
+    // MFMA results are read by VALU / stores next
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 64 * q + 4 * (4 * kq + r) + g;
+                const int tap = R / CINP, ci = R % CINP;
+                if (R < ROWS && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad on column strips, EXACT rows (round 4).  A strip is 32 output columns = 8 steps of 4 positions, so the K loop can
+// walk the REAL pixels of a strip row and still have every address a compile-time constant: a window is 16 steps = two
+// strip rows, step s of it reads the x operand at LDS slot (s / 8) * RS + 4 (s % 8) (+ tap) -- ds_read immediates -- and the
+// dpre operand of pixel (row s / 8, column 4 (s % 8) + lane group): a per-lane offset that depends on s % 8 only (8
+// registers, set up per unit) plus the row as the buffer load's scalar offset.  Against the padded walk of
+// the padded-position walk of wgrad_lin_strip_kernel: no fake positions (34 -> 32 MFMA columns per row: -5.9 % MFMAs), no lane-offset table
+// (2 VALU + 1 LDS read per step), no dpre cursor (7 SALU per step).  The narrower last strip of an image masks its
+// missing columns in those 8 registers (out-of-range offset -> 0), so any width >= 1 is covered; rows past a short
+// unit fall beyond the unit's buffer resource (-> 0).  Staging of the next tile, double buffering, AGPR parking and the
+// hand-counted waits are those of wgrad_pipe_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int CINP, int NCH, bool NT>
+__global__ __launch_bounds__(256, 1) void wgrad_rows_strip_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int TAPS = KH * KW;
+    constexpr int ROWS = TAPS * CINP;
+    constexpr int Q = (ROWS + 63) / 64;
+    constexpr int NQP = 4 / NCH;
+    constexpr int QW = (Q + NQP - 1) / NQP;
+    constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    constexpr int TWZ = 32;                  // strip width
+    constexpr int RSZ = TWZ + KW - 1;        // slots per tile row (the host plans exactly this)
+    constexpr int SPR = TWZ / 4;             // steps per strip row
+    constexpr int U = 2 * SPR;               // steps per unrolled window: two strip rows
+    constexpr int NSW = U / 2;               // staging passes per window: loads in its first half, LDS writes in its second
+    constexpr int LA = 2, RN = 3;            // LDS fragments in flight ahead of the MFMAs / fragment ring
+    constexpr int WINB = 2 * RSZ * PS * 4;   // LDS bytes from one window to the next
+    static_assert(QW * 16 >= 128, "AGPR parking assumes the accumulators fill the VGPRs (see wgrad_pipe_kernel)");
+    static_assert((U * QW) % RN == 0, "window must keep the fragment ring in phase");
+    static_assert(U == 16, "SRX_TAKE_OVER_B names the 16 registers of a window");
+    static_assert(QW >= 9, "the dealt-out schedule of a step uses gaps 0..8");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, qpart = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int co = cout0 + li;
+    const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;
+    const int c4 = tid % TPP, sp = tid / TPP;
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int buf_bytes = (a.zero_slot + 4) * PS * 4;   // (the host allocates 4 slots past the largest tile, per buffer)
+
+    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+    const int lds_base = (int)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+    int xw[QW];      // LDS byte address of (position kq of the running window's first step, the lane's tap / channels)
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        int R = 64 * q + 4 * li;
+        if (q >= Q || R >= ROWS) R = 0;
+        const int tap = R / CINP, ci = R % CINP;
+        xw[k] = lds_base + ((kq + (tap / KW) * RSZ + (tap % KW)) * PS + ci) * 4;
+    }
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 2 * buf_bytes / 16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
+    }
+    const int voff_lane = tid * 16;
+    const int wl_lane = (sp * PS + 4 * c4) * 4;
+    StageGeo SG;
+    constexpr int JP = (RSZ + PPP - 1) / PPP;
+    SG.JP1 = __builtin_amdgcn_readfirstlane(JP - 1);
+    SG.rowfix_g = __builtin_amdgcn_readfirstlane((a.W - JP * PPP) * CINP * 4);
+    SG.rowfix_l = __builtin_amdgcn_readfirstlane((RSZ - JP * PPP) * PS * 4);
+    SG.m_first = ~0ull; SG.m_last = ~0ull; SG.m_mid = ~0ull;     // (per tile, stage_setup)
+    SG.m_row = uniform64(__ballot((JP - 1) * PPP + sp < RSZ));
+    const int rowb = __builtin_amdgcn_readfirstlane(a.OW * a.Cout * 4);      // bytes of one image row of dpre
+    const int lane_b = (kq * a.Cout + co_c) * 4;                            // lane part of a dpre offset, column 0 of a step
+    const int colb = 4 * a.Cout * 4;                                        // bytes from one step's first column to the next
+
+    f32x4 acc[QW][4];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[k][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+
+    auto tile_of = [&](int uu_, int& n, int& h, int& th, int& ow0, int& tw) {
+        h = uu_ % a.OH;
+        n = uu_ / a.OH;
+        const int tx = n % a.NTX;
+        n = n / a.NTX;
+        ow0 = tx * TWZ;
+        tw = a.OW - ow0 < TWZ ? a.OW - ow0 : TWZ;
+        th = a.TH;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - uu_ < th) th = u1 - uu_;
+    };
+    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int ow0, int buf, bool active) {
+        const int left = __builtin_amdgcn_readfirstlane(active ? (th + KH - 1) * JP : 0);
+        const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;
+        qi.j = 0; qc.j = 0;
+        qi.off = __builtin_amdgcn_readfirstlane(((h - a.pad_t) * a.W + ow0) * CINP * 4);
+        qc.off = __builtin_amdgcn_readfirstlane(buf * buf_bytes);
+        // image column of tile slot c is ow0 - pad_l + c; a narrow last strip has invalid columns before the last pass too
+        const int iw0 = ow0 - a.pad_l + sp;
+        const unsigned long long v0 = __ballot(iw0 >= 0 && iw0 < a.W && sp < RSZ);
+        const int cl = (JP - 1) * PPP + sp;
+        const unsigned long long vl = __ballot(cl < RSZ && iw0 + (JP - 1) * PPP >= 0 && iw0 + (JP - 1) * PPP < a.W);
+        SG.m_first = uniform64(JP == 1 ? (v0 & vl) : v0);
+        SG.m_last = uniform64(vl);
+        SG.m_mid = uniform64(__ballot(iw0 + PPP >= 0 && iw0 + PPP < a.W));
+        qi.left = left; qc.left = left;
+        qi.thr = __builtin_amdgcn_readfirstlane(left - above);
+        qc.thr = 0;
+    };
+    auto x_rsrc = [&](int n) {
+        return uniform_rsrc(a.x + ((size_t)n * a.H * a.W - a.pad_l) * CINP, (a.H * a.W + a.pad_l) * CINP * 4);
+    };
+    // the unit's pixels: th rows, the last one ending after its tw columns (th == 0: nothing)
+    auto b_rsrc = [&](int n, int h, int th, int ow0, int tw) {
+        return uniform_rsrc(a.dpre + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout, th > 0 ? ((th - 1) * a.OW + tw) * a.Cout * 4 : 0);
+    };
+    // per-lane dpre offsets of the 8 steps of a strip row, for a strip of tw columns (columns >= tw: out of range -> 0)
+    int vpf[SPR];
+    auto set_vpf = [&](int tw) {
+#pragma unroll
+        for (int j = 0; j < SPR; ++j) vpf[j] = (4 * j + kq < tw) ? lane_b + j * colb : kOobOffset;
+    };
+
+    // dpre operands: bcur[] = the running window's (VGPRs), bnext[] = the next window's (in flight, AGPRs)
+    float bcur[U], bnext[U];
+#define SRX_TAKE_OVER_B()                                                                                          \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0) ; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15"                  \
+                     : "+a"(bnext[0]), "+a"(bnext[1]), "+a"(bnext[2]), "+a"(bnext[3]), "+a"(bnext[4]), "+a"(bnext[5]), \
+                       "+a"(bnext[6]), "+a"(bnext[7]), "+a"(bnext[8]), "+a"(bnext[9]), "+a"(bnext[10]),            \
+                       "+a"(bnext[11]), "+a"(bnext[12]), "+a"(bnext[13]), "+a"(bnext[14]), "+a"(bnext[15]));       \
+        _Pragma("unroll") for (int j = 0; j < U; ++j)                                                              \
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(bcur[j]) : "a"(bnext[j]));   /* (here, not next to the MFMA that uses it) */ \
+    } while (0)
+
+    int u = u0;
+    int n, h, th, ow0, tw;
+    tile_of(u, n, h, th, ow0, tw);
+    [[maybe_unused]] unsigned long long t_loop = 0, t_end = 0;   // (trace builds)
+    [[maybe_unused]] const unsigned long long t_begin = SRX_STAMP();
+    __syncthreads();
+    {
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h, th, ow0, 0, true);
+        stage_tile_scalar<CINP, 6, true, true>(qi, qc, SG, x_rsrc(n), voff_lane, wl_lane);
+        // the first unit's first window, all at once: ordinary (compiler-visible) loads
+        set_vpf(tw);
+        const __amdgpu_buffer_rsrc_t brs0 = b_rsrc(n, h, th, ow0, tw);
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            bnext[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs0, vpf[j % SPR], (j / SPR) * rowb, 0));
+        lds_barrier();
+        SRX_TAKE_OVER_B();
+    }
+    int cur_buf = 0;
+    while (u < u1) {
+        tile_of(u, n, h, th, ow0, tw);
+        const int un_ = u + th;
+        const bool has_next = un_ < u1;
+        int n2 = n, h2 = h, th2 = th, ow2 = ow0, tw2 = tw;
+        if (has_next) tile_of(un_, n2, h2, th2, ow2, tw2);
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h2, th2, ow2, cur_buf ^ 1, has_next);
+        const __amdgpu_buffer_rsrc_t xrs = x_rsrc(n2);
+        const __amdgpu_buffer_rsrc_t brs = b_rsrc(n, h, th, ow0, tw);
+        const __amdgpu_buffer_rsrc_t brs_next = b_rsrc(n2, h2, has_next ? th2 : 0, ow2, tw2);
+
+        const int nwin = (th + 1) >> 1;      // (an odd last row pair: its second row lies beyond the unit's resource -> 0)
+        auto read_x = [&](int k, int uu) -> f32x4 {
+            return *(lds_f32x4*)(uintptr_t)(unsigned)(xw[k] + ((uu / SPR) * RSZ + 4 * (uu % SPR)) * PS * 4);
+        };
+        f32x4 ring[RN];
+#pragma unroll
+        for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
+
+        const unsigned long long ts_l = SRX_STAMP();
+        __amdgpu_buffer_rsrc_t brs_pf = brs;
+        int spf0 = __builtin_amdgcn_readfirstlane(2 * rowb), spf1 = __builtin_amdgcn_readfirstlane(3 * rowb);   // rows of the window being prefetched
+        for (int wi = 0; wi < nwin; ++wi) {
+            if (wi + 1 == nwin) {
+                // the unit's last window prefetches the NEXT unit's first dpre window (nothing real when there is none)
+                brs_pf = brs_next;
+                spf0 = __builtin_amdgcn_readfirstlane(0);
+                spf1 = rowb;
+                set_vpf(tw2);
+            }
+            f32x4 stg[NSW];
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                const float b = bcur[uu];
+                bsum += b;
+                unsigned long long smk = 0, smt = 0, smr = 0;
+                int sso = 0;
+#pragma unroll
+                for (int k = 0; k < QW; ++k) {
+                    const int idx = (uu * QW + k) % RN;
+                    const int kk = k + LA;
+                    ring[(idx + LA) % RN] = read_x(kk % QW, uu + kk / QW);
+                    mfma4_wgrad(acc[k], ring[idx], b);
+                    if (uu >= NSW) {
+                        // LDS write of the pass issued NSW steps ago.  Younger memory operations that certainly
+                        // count: the two dpre loads of each first-half step after it.
+                        if (k == 0) stage_commit_a(2 * (NSW - 1 - (uu - NSW)), qc, stage_mask_row(qc, SG), wl_lane, stg[uu - NSW]);
+                        if (k == 4) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
+                        if (k == 2 && uu == NSW) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g);      // (the cursor step of pass NSW-1)
+                    } else {
+                        // dpre of steps 2uu, 2uu+1 of the next window: row uu / 4 of its two rows
+                        if (k == 1) bnext[2 * uu] = dpre_fire_tab_nt<NT>(brs_pf, vpf[(2 * uu) % SPR], (2 * uu) / SPR ? spf1 : spf0);
+                        if (k == 7) bnext[2 * uu + 1] = dpre_fire_tab_nt<NT>(brs_pf, vpf[(2 * uu + 1) % SPR], (2 * uu + 1) / SPR ? spf1 : spf0);
+                        // one pass of the next tile, in pieces
+                        if (k == 2) { if (uu > 0) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }
+                        if (k == 3) stage_mask_az<true>(qi, SG, smk, smt, smr);
+                        if (k == 4) stage_mask_bz(qi, smk, smt, smr, sso);
+                        if (k == 6) stg[uu] = stage_fire_za(smk, smr, sso, xrs, voff_lane);
+                    }
+                }
+            }
+            SRX_TAKE_OVER_B();
+            spf0 += 2 * rowb; spf1 += 2 * rowb;
+#pragma unroll
+            for (int k = 0; k < QW; ++k) { xw[k] += WINB; SRX_PIN(xw[k]); }
+        }
+        const unsigned long long ts_e = SRX_STAMP();
+        t_loop += ts_e - ts_l;
+        {
+            // back to the first window, in the other buffer
+            const int back = __builtin_amdgcn_readfirstlane((cur_buf ? -buf_bytes : buf_bytes) - nwin * WINB);
+#pragma unroll
+            for (int k = 0; k < QW; ++k) { xw[k] += back; SRX_PIN(xw[k]); }
+        }
+        stage_tile_scalar<CINP, 6, true, true>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        lds_barrier();
+        cur_buf ^= 1;
+        u = un_;
+        t_end += SRX_STAMP() - ts_e;
+    }
+#undef SRX_TAKE_OVER_B
+#ifdef SRX_TRACE
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_loop; tr[3] = t_end; tr[4] = 0;
     }
 #endif
 

@@ -20,6 +20,8 @@ hipError_t launch_l2(const float* w, const float* mask, size_t n, float scale, f
                      hipStream_t s);
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                        float gs, hipStream_t s);
+hipError_t launch_adam_dev(float* w, const float* g, float* m, float* v, size_t n, void* state, float b1, float b2, float eps,
+                           float gs, hipStream_t s);
 hipError_t launch_momentum(float* w, const float* g, float* acc, size_t n, float lr, float mom, float cap, float gs,
                            hipStream_t s);
 hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t rows, size_t row_len, float* loss,

@@ -859,6 +859,64 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
     }
 }
 
+// The same update with the step count and the learning rate in DEVICE memory, so that a captured HIP graph of a whole train
+// step can be replayed without a per-step kernel argument (ESPCN trains for 1.6 M steps of a dozen ~10-us launches,
+// espcn/makefile:30-36).  state: { int64 t; float lr; float lr_t (out, for inspection); uint32 blocks_done }.
+// Every block reads t BEFORE any block can have changed it: the increment is done by the block that finishes last
+// (a counter of finished blocks), i.e. after all of them have read it.  lr_t is evaluated by one thread per block in
+// double precision with the same expression as the host path (srx_adam_tf_step).
+struct AdamState {
+    long long t;
+    float lr, lr_t;
+    unsigned done, pad;
+};
+__global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                          AdamState* __restrict__ st, float b1, float b2, float eps, float gs) {
+    __shared__ float sh_lr_t;
+    if (threadIdx.x == 0) {
+        const double t = (double)(__atomic_load_n(&st->t, __ATOMIC_RELAXED) + 1);
+        sh_lr_t = (float)((double)st->lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
+    __syncthreads();
+    const float lr_t = sh_lr_t;
+    const size_t n4 = n >> 2;
+    const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * gs;
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] = b1 * mv[e] + ob1 * gv[e];
+            vv[e] = b2 * vv[e] + ob2 * gv[e] * gv[e];
+            wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(w)[i] = wv;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float gi = g[i] * gs;
+            const float mi = b1 * m[i] + ob1 * gi;
+            const float vi = b2 * v[i] + ob2 * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&st->done, 1u) == gridDim.x - 1) {      // every block has read t: the last one to finish advances it
+            st->done = 0;
+            st->lr_t = lr_t;
+            __atomic_store_n(&st->t, st->t + 1, __ATOMIC_RELAXED);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void momentum_clip_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                             float* __restrict__ acc, size_t n, float lr, float mom,
                                                             float cap, float gs) {
@@ -880,6 +938,12 @@ static int ew_grid(size_t n, int per_thread) {
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                        float eps, float gs, hipStream_t s) {
     hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, gs);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam_dev(float* w, const float* g, float* m, float* v, size_t n, void* state, float b1, float b2,
+                           float eps, float gs, hipStream_t s) {
+    hipLaunchKernelGGL(adam_tf_dev_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, w, g, m, v, n, reinterpret_cast<AdamState*>(state), b1, b2, eps, gs);
     return hipGetLastError();
 }
 

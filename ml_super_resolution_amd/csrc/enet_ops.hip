@@ -786,11 +786,15 @@ int srx_gemm(const srx_gemm_desc* d, const float* A, const float* B, const float
     const bool rows_a = d->a_col_stride == 1 || d->M == 1;
     // skinny routes (M <= 16, one matrix): forward of a dense layer ...
     const long nn_splits = d->batch == 1 ? gemm_skinny_nn_splits(d->M, d->N, d->K) : 0;
-    if (nn_splits && have_ws && d->b_col_stride == 1 && (d->b_row_stride & 3) == 0 && al16(B)) {
+    // (its K slice of the M <= 16 rows of A lives in dynamic LDS: only while that stays below the 64-KiB launch limit --
+    // N = K = 65536 with M <= 4 would ask for 128 KiB; such shapes fall through to the 64 x 64-tile kernel)
+    const int nn_mt = d->M <= 4 ? 4 : (d->M <= 8 ? 8 : 16);
+    const size_t nn_lds = nn_splits ? (size_t)nn_mt * (size_t)(((d->K + nn_splits - 1) / nn_splits + 15) / 16 * 16) * sizeof(float) : 0;
+    if (nn_splits && nn_lds <= 48 * 1024 && have_ws && d->b_col_stride == 1 && (d->b_row_stride & 3) == 0 && al16(B)) {
         g.splits = (int)nn_splits;
         g.ksplit = (int)(((d->K + nn_splits - 1) / nn_splits + 15) / 16 * 16);
         g.part = (float*)ws;
-        const int mt = d->M <= 4 ? 4 : (d->M <= 8 ? 8 : 16);
+        const int mt = nn_mt;
         const dim3 grid((unsigned)((d->N + 1023) / 1024), (unsigned)g.splits);
         const size_t lds = (size_t)mt * g.ksplit * sizeof(float);
         if (mt == 4) hipLaunchKernelGGL(gemm_skinny_nn_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, g);

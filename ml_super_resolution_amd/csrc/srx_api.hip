@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_nt;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -38,6 +38,8 @@ Knobs read_knobs() {
     k.stagger = env_int("SRX_STAGGER", -1);
     k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
+    k.wgrad_pipe_strip = env_int("SRX_WGRAD_PIPE_STRIP", 1);   // 0: column-strip filter gradients on the two-workgroup kernel (A/B)
+    k.wgrad_nt = env_int("SRX_WGRAD_NT", 1);                   // strip filter gradient: dpre loads marked non-temporal (A/B)
     k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
     k.subpixel_grid = env_int("SRX_SUBPIXEL_GRID", 0);
@@ -57,6 +59,10 @@ const Knobs& knobs() { static const Knobs k = read_knobs(); return k; }
 // conv kernel family, see srx_set_conv_path: -1 = not set by the caller (the environment's default applies)
 std::atomic<int> g_use_pipe{-1};
 int use_pipe() { const int v = g_use_pipe.load(std::memory_order_relaxed); return v < 0 ? knobs().pipe_default : v; }
+// filter-gradient kernel family, see srx_set_wgrad_path: -1 = not set by the caller (the environment's defaults apply)
+std::atomic<int> g_wgrad_path{-1};
+int wgrad_path_default() { return !knobs().wgrad_lin ? 0 : ((knobs().wgrad_pipe || knobs().wgrad_pipe_strip) ? 2 : 1); }
+int wgrad_path() { const int v = g_wgrad_path.load(std::memory_order_relaxed); return v < 0 ? wgrad_path_default() : v; }
 
 // Compute units of the current device (persistent-workgroup grids are sized from it): queried once per device.
 // Without a device (host-only workspace queries on a build box) the MI355X's 256.
@@ -407,6 +413,10 @@ int srx_set_conv_path(int pipelined) {
     const int old = g_use_pipe.exchange(pipelined ? 1 : 0, std::memory_order_relaxed);
     return old < 0 ? knobs().pipe_default : old;
 }
+int srx_set_wgrad_path(int path) {
+    const int old = g_wgrad_path.exchange(path < 0 ? -1 : (path > 2 ? 2 : path), std::memory_order_relaxed);
+    return old < 0 ? wgrad_path_default() : old;
+}
 size_t srx_reduce_scratch_bytes(void) { return (size_t)kReduceBlocks * sizeof(float); }
 
 size_t srx_conv2d_workspace_bytes(const srx_conv_desc* d, int op) {
@@ -493,7 +503,7 @@ static int bwd_data_impl(const srx_conv_desc* d, const float* dpre, const float*
 // the layer to the cursor kernel (the EnhanceNet generator's residual blocks at 64 x 32 x 32; at that size either kernel
 // takes 58 us -- the launch is latency-bound -- but larger batches of such rows are not).  One row less and it fits.  The grid (= number of partial filters = workspace size) does not depend on the tile height.
 static void wgrad_tile_for_linear_walk(const srx_conv_desc* d, Plan* p) {
-    if (p->NTX != 1 || !knobs().wgrad_lin) return;
+    if (p->NTX != 1 || wgrad_path() < 1) return;
     const size_t slot_bytes = (size_t)((p->cinp == 4) ? 4 : p->cinp + 4) * 4;
     while (p->TH > 1 && p->lds_bytes + 4 * slot_bytes > 80 * 1024) {
         p->TH -= 1;
@@ -536,7 +546,8 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     hipError_t err = hipSuccess;
     hipStream_t s = (hipStream_t)stream;
     // Linear-walk kernel for full-width tiles (see wgrad_lin_kernel); SRX_WGRAD_LIN=0 selects the cursor kernel (A/B).
-    const int use_lin = knobs().wgrad_lin && !s2;       // (stride 2: the cursor kernel, whose pixel cursor simply steps two slots)
+    const int wpath = wgrad_path();                     // 0 cursor kernel, 1 two-workgroup linear walk, 2 one-workgroup pipelined (default)
+    const int use_lin = wpath >= 1 && !s2;              // (stride 2: the cursor kernel, whose pixel cursor simply steps two slots)
     const int kPipeGrid = pipe_grid();
     const bool lin_ok = use_lin && p.NTX == 1 && OW >= 4 && p.RS >= 8 && p.RS == d->W + pl && (long)p.TH * OW * d->Cout * 4 < (1L << 30) &&
                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096;
@@ -544,7 +555,7 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     const size_t lin_lds = p.lds_bytes + 4 * (size_t)((p.cinp == 4) ? 4 : p.cinp + 4) * 4;
     // one workgroup per CU, two tile buffers (wgrad_pipe_kernel): exact-fit channels, a row stride of at least one pass;
     // SRX_WGRAD_PIPE=0 keeps the two-workgroup kernel (A/B)
-    const int use_wpipe = knobs().wgrad_pipe;
+    const int use_wpipe = wpath >= 2 && knobs().wgrad_pipe;
     const int wppp = (p.cinp >= 16) ? 256 / (p.cinp / 4) : 256;
     int wgrid = p.grid;
     bool wdone = false;
@@ -579,6 +590,17 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     const bool lin_strip_ok = use_lin && p.NTX > 1 && d->Cin == p.cinp && p.RS >= wppp && p.TW >= 4 && lin_lds <= 80 * 1024 &&
                               (OW % p.TW == 0 || OW % p.TW >= 4) && p.RS <= 3 * wppp &&
                               (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096 && (long)OH * OW * d->Cout * 4 < (1L << 30);
+    // ... on one workgroup per CU with two tile buffers, exact rows (wgrad_rows_strip_kernel): a 32-column strip row is 8
+    // whole steps, so the K loop walks real pixels only -- no fake positions, any last-strip width >= 1;
+    // SRX_WGRAD_PIPE_STRIP=0 / srx_set_wgrad_path(1) keep the two-workgroup padded walk (A/B).
+    const bool rows_ok = wpath >= 2 && knobs().wgrad_pipe_strip && !s2 && p.NTX > 1 && p.TW == 32 && p.RS == 32 + d->KW - 1 &&
+                         d->Cin == p.cinp && 2 * lin_lds <= 160 * 1024 &&
+                         (long)d->H * d->W * d->Cin * 4 < (1L << 31) - 4096 && (long)OH * OW * d->Cout * 4 < (1L << 30);
+    if (!wdone && rows_ok) {
+        wgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+        wdone = launch_wgrad_rows_strip(k, a, wgrid, 2 * lin_lds, knobs().wgrad_nt != 0, s, &err);
+        if (!wdone) wgrid = p.grid;
+    }
     if (wdone) {
     } else if (lin_strip_ok && launch_wgrad_lin_strip(k, a, p.grid, lin_lds, s, &err)) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
@@ -623,7 +645,7 @@ void blocked_desc(srx_conv_desc* d, int N, int H, int W) {
 // Returns 0 (one launch per pair), 1 (full-width tiles) or 2 (column strips).
 int pairs_route(const srx_conv_desc* d, const Plan& p, int pairs, int* G, size_t* lin_lds) {
     *lin_lds = p.lds_bytes + 4 * (size_t)(p.cinp + 4) * 4;
-    const bool common = knobs().wgrad_lin && p.cinp == 64 && p.nch == 4 && d->W >= 4 && p.RS >= 8 && *lin_lds <= 80 * 1024 &&
+    const bool common = wgrad_path() >= 1 && p.cinp == 64 && p.nch == 4 && d->W >= 4 && p.RS >= 8 && *lin_lds <= 80 * 1024 &&
                         (long)d->H * d->W * 64 * 4 < (1L << 31) - 4096;
     const bool lin_ok = common && p.NTX == 1 && p.RS == d->W + p.pad_l && (long)p.TH * d->W * 64 * 4 < (1L << 30);
     const int wppp = 256 / (64 / 4);
@@ -782,6 +804,15 @@ int srx_adam_tf_step(float* w, const float* g, float* m, float* v, size_t numel,
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
     SRX_CHECK_LAUNCH(launch_adam(w, g, m, v, numel, (float)lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream),
                      "adam");
+}
+
+int srx_adam_tf_step_dev(float* w, const float* g, float* m, float* v, size_t numel, void* state, float beta1, float beta2,
+                         float eps, float grad_scale, srx_stream_t stream) {
+    if (!w || !g || !m || !v || !state) return fail(SRX_ERR_BAD_ARG, "null pointer");
+    if (!aligned16(w) || !aligned16(g) || !aligned16(m) || !aligned16(v) || !aligned16(state))
+        return fail(SRX_ERR_ALIGN, "flat buffers and the state block must be 16-byte aligned");
+    if (numel == 0) return fail(SRX_ERR_BAD_ARG, "adam (device state): empty parameter buffer (the step count would not advance)");
+    SRX_CHECK_LAUNCH(launch_adam_dev(w, g, m, v, numel, state, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "adam (device state)");
 }
 
 int srx_momentum_clip_step(float* w, const float* g, float* acc, size_t numel, float lr, float momentum, float cap,

@@ -5,4 +5,13 @@ bool launch_wgrad_pipe(const ConvKey& k, const WgradArgs& a, int grid, size_t ld
     SRX_WGRAD_PIPE_CASE(3, 3, 64, 4)
     return false;
 }
+// column strips, exact rows (windows of two 32-column strip rows)
+bool launch_wgrad_rows_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, bool nt, hipStream_t s, hipError_t* err) {
+    if (k.kh == 3 && k.kw == 3 && k.cinp == 64 && k.nch == 4) {
+        *err = nt ? launch_with_lds(wgrad_rows_strip_kernel<3, 3, 64, 4, true>, a, grid, lds, s)
+                  : launch_with_lds(wgrad_rows_strip_kernel<3, 3, 64, 4, false>, a, grid, lds, s);
+        return true;
+    }
+    return false;
+}
 }  // namespace srx

@@ -245,6 +245,33 @@ def adam_tf_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale
                                  float(beta2), float(eps), int(t), float(grad_scale), _stream()), 'srx_adam_tf_step')
 
 
+def adam_state(device, t=0, lr=0.0):
+    """The 32-byte device block srx_adam_tf_step_dev works on: {int64 t; float lr; float lr_t; uint32 done, pad} (+ padding)."""
+    st = torch.zeros(8, dtype=torch.int32, device=device)
+    adam_state_set(st, t=t, lr=lr)
+    return st
+
+
+def adam_state_set(st, t=None, lr=None):
+    if t is not None:
+        st[0:2].copy_(torch.tensor([int(t)], dtype=torch.int64).view(torch.int32))
+    if lr is not None:
+        st[2:3].copy_(torch.tensor([float(lr)], dtype=torch.float32).view(torch.int32))
+
+
+def adam_state_get(st):
+    """(t, lr, lr_t) -- synchronises; for tests and checkpoints."""
+    h = st.cpu()
+    return int(h[0:2].view(torch.int64).item()), float(h[2:3].view(torch.float32).item()), float(h[3:4].view(torch.float32).item())
+
+
+def adam_tf_step_dev(w, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    for tns, n in ((w, 'w'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _chk(tns, n)
+    check(lib().srx_adam_tf_step_dev(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), _ptr(state), float(beta1), float(beta2),
+                                     float(eps), float(grad_scale), _stream()), 'srx_adam_tf_step_dev')
+
+
 def momentum_clip_step(w, g, acc, lr, momentum=0.9, cap=float('inf'), grad_scale=1.0):
     for tns, n in ((w, 'w'), (g, 'g'), (acc, 'acc')):
         _chk(tns, n)

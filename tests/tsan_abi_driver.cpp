@@ -22,12 +22,14 @@ bool launch_wgrad_narrow(const ConvKey&, const WgradArgs&, int, hipStream_t, hip
 bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 hipError_t launch_reduce_partials(const float*, int, int, int, int, float*, float*, const float*, float, hipStream_t) { return hipSuccess; }
 hipError_t launch_reduce_partials_pairs(const float*, int, int, int, int, float*, float*, int, int, hipStream_t) { return hipSuccess; }
+bool launch_wgrad_rows_strip(const ConvKey&, const WgradArgs&, int, size_t, bool, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
 bool launch_wgrad_lin_pairs(const ConvKey&, const WgradPairs&, int, int, bool, size_t, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
 hipError_t launch_subpixel(const float*, float*, int, int, int, int, int, bool, const SubpixelTune&, hipStream_t) { return hipSuccess; }
 hipError_t launch_stream_copy(const float*, float*, size_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_mse(const float*, const float*, size_t, float, float*, int, float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_l2(const float*, const float*, size_t, float, float*, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_adam(float*, const float*, float*, float*, size_t, float, float, float, float, float, hipStream_t) { return hipSuccess; }
+hipError_t launch_adam_dev(float*, const float*, float*, float*, size_t, void*, float, float, float, float, hipStream_t) { return hipSuccess; }
 hipError_t launch_momentum(float*, const float*, float*, size_t, float, float, float, float, hipStream_t) { return hipSuccess; }
 hipError_t launch_rownorm_loss(const float*, const float*, size_t, size_t, float*, float*, float*, hipStream_t) { return hipSuccess; }
 size_t ssim_scratch_bytes(int N) { return (size_t)N * 64; }
