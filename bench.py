@@ -340,7 +340,42 @@ def extras(model, dev, stream, x64, y64, px):
         c3()
     out['srcnn_c1_three_launches_us'] = round(hip_event_time_ms(c3, 100, stream) * 1e3, 2)
     out['srcnn_c1_path'] = 'one launch: 9-1-5 chained through LDS per 15x15 output tile (srx_srcnn_forward), bit-identical to the three launches'
-    del sm, img, e3, lr
+    del img, lr
+    # -- the small networks' TRAIN steps (espcn/makefile:30-36: batch 64 of 17x17 LR patches, 1.6 M steps; srcnn/srcnn.py:14-16,
+    #    28-40: batch 64 of 243x243 crops): forward + loss + backward + Adam replayed as one HIP graph per batch shape
+    try:
+        eb = 64
+        elr = torch.rand((eb, 17, 17, 3), device=dev) * 2 - 1
+        ehr = torch.rand((eb, 17, 17, 27), device=dev) * 2 - 1
+        for _ in range(6):
+            e3.train_step(elr, ehr, 1e-3)
+        us_g = hip_event_time_ms(lambda: e3.train_step(elr, ehr, 1e-3), 200, stream) * 1e3
+        e3.stack.use_step_graph = False
+        for _ in range(3):
+            e3.train_step(elr, ehr, 1e-3)
+        us_e = hip_event_time_ms(lambda: e3.train_step(elr, ehr, 1e-3), 200, stream) * 1e3
+        out['espcn_train_us'] = {'batch': eb, 'patch': '17x17 LR, r = 3', 'graph_replay_us': round(us_g, 2), 'eager_launches_us': round(us_e, 2),
+                                 'speedup': round(us_e / us_g, 3), 'patches_per_s': round(eb / (us_g * 1e-6), 0),
+                                 'what': 'ESPCN train step (3 fwd, MSE, 3 wgrad + reduce, 2 dgrad, TF-Adam with device-resident step count) as ONE replayed HIP graph vs the same launches issued eagerly'}
+    except Exception as exc:
+        out['espcn_train_us'] = {'error': repr(exc)}
+    try:
+        sb = 64
+        ssd = torch.rand((sb, 243, 243, 3), device=dev) * 2 - 1
+        shd = torch.rand((sb, 231, 231, 3), device=dev) * 2 - 1
+        for _ in range(4):
+            sm.train_step(ssd, shd)
+        ms_g = hip_event_time_ms(lambda: sm.train_step(ssd, shd), 10, stream)
+        # fwd MACs per output pixel: 9*9*3*64 at 235^2, 64*32 at 235^2, 5*5*32*3 at 231^2; backward: wgrad of all three + dgrad of layers 2, 3
+        f1, f2, f3 = 2.0 * 81 * 3 * 64 * 235 * 235, 2.0 * 64 * 32 * 235 * 235, 2.0 * 25 * 32 * 3 * 231 * 231
+        flop = sb * (2 * f1 + 3 * f2 + 3 * f3)
+        out['srcnn_train_ms'] = {'batch': sb, 'crop': '243x243 -> 231x231', 'train_ms': round(ms_g, 3), 'images_per_s': round(sb / (ms_g * 1e-3), 1),
+                                 'tflops': round(flop / (ms_g * 1e-3) / 1e12, 2), 'frac_of_fp32_mfma_peak': round(flop / (ms_g * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'what': 'SRCNN 9-1-5 train step (row-norm loss, Adam(1e-3, .5, .9)) at the reference\'s batch of 64 crops of 243x243; algorithmic FLOPs (3 input channels unpadded)'}
+        del ssd, shd
+    except Exception as exc:
+        out['srcnn_train_ms'] = {'error': repr(exc)}
+    del sm, e3
     # -- BASELINE configs[4] as the reference trains it (enet/enet/experiment_train.py:15-22): EnhanceNet-PAT, batch 64 of
     #    32x32 -> 128x128 patches, VGG-19 perceptual + texture + adversarial losses (random VGG-shaped weights: the real
     #    ones are not available offline -- timing only).  One cycle of the schedule = 1 discriminator + 3 generator runs.

@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_nt;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_nt, kwrows_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -39,6 +39,7 @@ Knobs read_knobs() {
     k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
     k.wgrad_pipe_strip = env_int("SRX_WGRAD_PIPE_STRIP", 1);   // 0: column-strip filter gradients on the two-workgroup kernel (A/B)
+    k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 60000);   // 5x5 32->3 on conv_kwrows_kernel from this many output pixels (negative: never)
     k.wgrad_nt = env_int("SRX_WGRAD_NT", 1);                   // strip filter gradient: dpre loads marked non-temporal (A/B)
     k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
@@ -313,6 +314,13 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
             if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
             return SRX_OK;
         }
+    }
+    // SRCNN's 5x5 32 -> 3 reconstruction layer on large inputs: (kw, co) pairs as the MFMA's rows -- see conv_kwrows.hip.
+    // Results agree with the kernels below to rounding (another summation order), so the route starts beyond the window
+    // of the one-launch SRCNN kernel, whose tests demand bit-equality with these per-layer launches.
+    if (knobs().kwrows_min_pixels >= 0 && launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err)) {
+        if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+        return SRX_OK;
     }
     // Its lean staging cursor / sub-tile walk / buffer-store epilogue cover: exact-fit channels, full-width
     // tiles, a row stride of at least one staging pass, sub-tile steps of at most one row, 16-byte output

@@ -87,6 +87,13 @@ class ConvStack(object):
         # variable leaf names: tf.layers.conv2d creates <scope>/kernel, <scope>/bias; tf.contrib.layers.convolution2d
         # (SRCNN, srcnn/srcnn.py:100-130) creates <scope>/weights, <scope>/biases
         self.kernel_name, self.bias_name = 'kernel', 'bias'
+        # ---- Adam with its step count and learning rate in device memory, and whole train steps replayed as HIP graphs
+        # (train_step_replay): ESPCN / SRCNN steps are a dozen dependent launches of ~10 us each, their recipes run 1.6 M
+        # of them (espcn/makefile:30-36).  SRX_STEP_GRAPH=0: every step as eager launches.
+        self.use_step_graph = os.environ.get('SRX_STEP_GRAPH', '1') != '0'
+        self._adam_state = None     # ops.adam_state(): {int64 t; float lr; ...} on the device
+        self._state_t, self._state_lr = None, None    # host mirror of what the device block holds
+        self._step_graphs = {}
 
     # ---- parameter views -------------------------------------------------------------------
     def kernel(self, i, buf=None):
@@ -128,6 +135,8 @@ class ConvStack(object):
     def _buf(self, key, shape):
         t = self._bufs.get(key)
         if t is None or tuple(t.shape) != tuple(shape):
+            if t is not None:
+                self._step_graphs.clear()      # a captured step points at the buffer that is about to be released
             t = torch.empty(shape, dtype=torch.float32, device=self.device)
             self._bufs[key] = t
         return t
@@ -176,7 +185,9 @@ class ConvStack(object):
         inv = 1.0 / (y.numel() if numel_global is None else numel_global)
         if self.loss_kind == 'rownorm':
             # srcnn/srcnn.py:142-144: mean over rows of ||reshape(diff, [-1, bb*bb])||_2
-            dy = ops.rownorm_loss_fwd_bwd(y, target, y.shape[1] * y.shape[2], self.loss)
+            row_len = y.shape[1] * y.shape[2]
+            dy = ops.rownorm_loss_fwd_bwd(y, target, row_len, self.loss, dpred=self._buf(('dy', 0), y.shape),
+                                          norms=self._buf(('rownorms',), (y.numel() // row_len,)))
         else:
             dy = self._buf(('dy', 0), y.shape)
             ops.mse_fwd_bwd(y, target, self.loss, inv_numel=inv, accumulate=False, dpred=dy)
@@ -191,6 +202,7 @@ class ConvStack(object):
         need = max(ops.bwd_filter_workspace_bytes(acts[i].shape, s.kernel_shape, s.padding)
                    for i, s in enumerate(self.specs))
         if self._ws is None or self._ws.numel() * 4 < need:
+            self._step_graphs.clear()
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
             self._ws2 = None
         # dgrad of layer i and wgrad (+ partial reduce) of layer i are independent: both only read dpre_i.  With
@@ -279,6 +291,96 @@ class ConvStack(object):
             self.opt_v = torch.zeros_like(self.params)
         self.global_step += 1
         ops.adam_tf_step(self.params, self.grads, self.opt_m, self.opt_v, lr, self.global_step, beta1, beta2, eps)
+
+    # ---- the same with the step count and the learning rate in device memory -------------------
+    def _sync_adam_state(self, lr):
+        """The device block {t, lr} follows the host's `global_step` (a checkpoint load, dist.attach) and the fed rate;
+        written only when one of them changed."""
+        if self._adam_state is None:
+            self._adam_state = ops.adam_state(self.device, t=self.global_step, lr=lr)
+            self._state_t, self._state_lr = self.global_step, float(lr)
+        if self._state_t != self.global_step:
+            ops.adam_state_set(self._adam_state, t=self.global_step)
+            self._state_t = self.global_step
+        if self._state_lr != float(lr):
+            ops.adam_state_set(self._adam_state, lr=lr)
+            self._state_lr = float(lr)
+
+    def adam_step_dev(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """adam_step through srx_adam_tf_step_dev: no per-step kernel argument, so the launch can sit in a replayed graph."""
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.params)
+            self.opt_v = torch.zeros_like(self.params)
+        self._sync_adam_state(lr)
+        ops.adam_tf_step_dev(self.params, self.grads, self.opt_m, self.opt_v, self._adam_state, beta1, beta2, eps)
+        self.global_step += 1
+        self._state_t += 1
+
+    def train_step_replay(self, x, target, lr, beta1=0.9, beta2=0.999, eps=1e-8, momentum=None, gradient_cap=0.01):
+        """forward + loss_and_backward + optimizer as ONE replayed HIP graph per (input shape, target shape, optimizer
+        constants).  momentum=None: TF-Adam with the step count and the learning rate in device memory
+        (srx_adam_tf_step_dev) -- a changing rate needs no new graph; momentum=m: Momentum on clipped gradients
+        (momentum_clip_step), whose rate is a kernel argument: the graph is keyed by it (VDSR's schedule changes it every
+        few thousand steps).  The first two steps of a shape run as eager launches (they are real steps: buffers, workspaces
+        and kernel attributes come into being), the third is captured -- capturing executes nothing -- and replayed, like
+        every step after it.  Eager and replayed steps issue the same kernels with the same arguments: the weights are
+        bit-identical either way (tests/test_gpu_models.py).  Falls back to eager launches when a gradient hook (data
+        parallelism) is attached or SRX_STEP_GRAPH=0.  Returns the device scalar of the loss."""
+        def optimizer_launch():
+            if momentum is None:
+                ops.adam_tf_step_dev(self.params, self.grads, self.opt_m, self.opt_v, self._adam_state, beta1, beta2, eps)
+            else:
+                ops.momentum_clip_step(self.params, self.grads, self.opt_m, lr, momentum, gradient_cap / lr)
+
+        def eager(xx, tt):
+            self.forward(xx, keep=True)
+            self.loss_and_backward(tt)
+            if momentum is None:
+                self.adam_step_dev(lr, beta1, beta2, eps)
+            else:
+                self.momentum_clip_step(lr, momentum, gradient_cap)
+            return self.loss
+        if not self.use_step_graph or self.grad_hook is not None or self.device.type != 'cuda' or self.overlap_wgrad or self.overlap_reduce:
+            return eager(x, target)
+        opt_key = (float(beta1), float(beta2), float(eps)) if momentum is None else ('momentum', float(lr), float(momentum), float(gradient_cap))
+        key = (tuple(x.shape), tuple(target.shape)) + opt_key
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            if len(self._step_graphs) >= 4:
+                self._step_graphs.clear()
+            ent = self._step_graphs[key] = {'warm': 0, 'graph': None}
+        if ent['graph'] is None:
+            if ent['warm'] < 2:
+                ent['warm'] += 1
+                loss = eager(x, target)
+                if key not in self._step_graphs:         # (the first step of a new shape replaced buffers: start over, warm)
+                    self._step_graphs[key] = ent
+                return loss
+            if self.opt_m is None:
+                self.opt_m = torch.zeros_like(self.params)
+                if momentum is None:
+                    self.opt_v = torch.zeros_like(self.params)
+            if momentum is None:
+                self._sync_adam_state(lr)
+            sx, st = x.clone(), target.clone()
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward(sx, keep=True)
+                self.loss_and_backward(st)
+                optimizer_launch()
+            ent.update(graph=g, x=sx, t=st)
+        if momentum is None:
+            self._sync_adam_state(lr)
+        if x.data_ptr() != ent['x'].data_ptr():
+            ent['x'].copy_(x)
+        if target.data_ptr() != ent['t'].data_ptr():
+            ent['t'].copy_(target)
+        ent['graph'].replay()
+        self.global_step += 1
+        if momentum is None:
+            self._state_t += 1
+        return self.loss
 
     def momentum_clip_step(self, lr, momentum=0.9, gradient_cap=0.01):
         """model_vdsr.py:158-184: clip every gradient element to +-gradient_cap/lr, then Momentum."""

@@ -124,10 +124,8 @@ class EspcnModel(object):
     def train_step(self, lr_source, hr_target, learning_rate):
         """MSE in sub-pixel space (hr_target is the space-to-depth label, dataset.py:140-156) + Adam
         with the fed learning rate (model_espcn.py:76-89)."""
-        self.stack.forward(lr_source, keep=True)
-        loss = self.stack.loss_and_backward(hr_target)
-        self.stack.adam_step(learning_rate)
-        return loss
+        # one replayed HIP graph per batch shape (engine.ConvStack.train_step_replay): a step is a dozen dependent launches
+        return self.stack.train_step_replay(lr_source, hr_target, learning_rate)
 
     # ---- checkpoints ---------------------------------------------------------------------------
     def save(self, path):

@@ -280,14 +280,17 @@ def momentum_clip_step(w, g, acc, lr, momentum=0.9, cap=float('inf'), grad_scale
                                        float(grad_scale), _stream()), 'srx_momentum_clip_step')
 
 
-def rownorm_loss_fwd_bwd(pred, target, row_len, loss_out, want_grad=True):
-    """SRCNN loss: mean over rows of ||reshape(pred-target, [-1,row_len])||_2 (+ its gradient)."""
-    _chk(pred, 'pred'); _chk(target, 'target')
+def rownorm_loss_fwd_bwd(pred, target, row_len, loss_out, want_grad=True, dpred=None, norms=None):
+    """SRCNN loss: mean over rows of ||reshape(pred-target, [-1,row_len])||_2 (+ its gradient).  dpred / norms: caller-owned
+    output / scratch tensors (a captured train step must not allocate)."""
+    _chk(pred, 'pred'); _chk(target, 'target'); _chk(dpred, 'dpred'); _chk(norms, 'norms')
     rows = pred.numel() // row_len
     if rows * row_len != pred.numel():
         raise ValueError('numel %d not divisible by row_len %d' % (pred.numel(), row_len))
-    norms = torch.empty(rows, dtype=torch.float32, device=pred.device)
-    dpred = torch.empty_like(pred) if want_grad else None
+    if norms is None:
+        norms = torch.empty(rows, dtype=torch.float32, device=pred.device)
+    if dpred is None and want_grad:
+        dpred = torch.empty_like(pred)
     check(lib().srx_rownorm_loss_fwd_bwd(_ptr(pred), _ptr(target), rows, row_len, _ptr(loss_out), _ptr(dpred),
                                          _ptr(norms), _stream()), 'srx_rownorm_loss_fwd_bwd')
     return dpred

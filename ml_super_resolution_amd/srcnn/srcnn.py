@@ -120,10 +120,8 @@ class SrcnnModel(object):
 
     def train_step(self, sd_images, hd_images_cropped):
         """hd_images_cropped: ground truth cropped to the VALID region (srcnn.py:132-136)."""
-        self.stack.forward(sd_images, keep=True)
-        loss = self.stack.loss_and_backward(hd_images_cropped)
-        self.stack.adam_step(0.001, beta1=0.5, beta2=0.9)          # srcnn.py:155-157
-        return loss
+        # srcnn.py:155-157: AdamOptimizer(0.001, beta1=0.5, beta2=0.9); one replayed HIP graph per batch shape
+        return self.stack.train_step_replay(sd_images, hd_images_cropped, 0.001, beta1=0.5, beta2=0.9)
 
     def run(self, keys, feed_dict):
         from .. import ops

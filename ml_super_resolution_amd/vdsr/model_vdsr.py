@@ -48,13 +48,11 @@ class VdsrModel(object):
         """One `session.run(trainer)`: forward, loss (MSE + L2), backward, optimizer, step += 1.
         Returns the device scalar holding the loss of THIS forward (pre-update weights)."""
         lr = self.learning_rate if learning_rate is None else learning_rate
-        self.stack.forward(sd_images, keep=True)
-        loss = self.stack.loss_and_backward(hd_images)
+        # one replayed HIP graph per batch shape (engine.ConvStack.train_step_replay; eager launches under data parallelism):
+        # ~100 launches per step, at the reference's default batches their host-side issue would otherwise bound the step
         if self.use_adam:
-            self.stack.adam_step(lr)                                   # model_vdsr.py:145-148
-        else:
-            self.stack.momentum_clip_step(lr, 0.9, gradient_cap=0.01)  # model_vdsr.py:158-184
-        return loss
+            return self.stack.train_step_replay(sd_images, hd_images, lr)                          # model_vdsr.py:145-148
+        return self.stack.train_step_replay(sd_images, hd_images, lr, momentum=0.9, gradient_cap=0.01)   # model_vdsr.py:158-184
 
     def taps(self):
         """conv.i / relu.i are the same post-ReLU tensor (tf.layers.conv2d already applied the

@@ -228,8 +228,18 @@ def test_bench_default_line_has_the_contract_keys():
     c = line['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert abs(line['value'] - 256 * 1000.0 / line['ms_per_step']) < 0.01 * line['value']
-    for key in ('dgrad', 'wgrad', 'subpixel', 'espcn_c2_us', 'srcnn_c1_us', 'enet_pat', 'fwd_hr_mpix_per_s'):
+    for key in ('dgrad', 'wgrad', 'subpixel', 'espcn_c2_us', 'srcnn_c1_us', 'enet_pat', 'fwd_hr_mpix_per_s',
+                'vdsr_recipe_64x128', 'srcnn_c1_cpu_ms', 'espcn_c2_cpu_ms', 'espcn_train_us', 'srcnn_train_ms'):
         assert key in line, key
+    rec = line['vdsr_recipe_64x128']
+    assert 'error' not in rec, rec
+    assert rec['train_ms'] > 0 and 0.3 < rec['train_frac_of_fp32_mfma_peak'] < 1.0
+    for k in ('fwd', 'dgrad', 'wgrad'):
+        assert 0.3 < rec[k]['frac'] < 1.0, (k, rec[k])
+    for k in ('srcnn_c1_cpu_ms', 'espcn_c2_cpu_ms'):
+        assert line[k]['port_ms'] > 0 and line[k]['library_ms'] > 0 and line[k]['cores'] >= 1, line[k]
+    assert 'error' not in line['espcn_train_us'] and line['espcn_train_us']['graph_replay_us'] > 0, line['espcn_train_us']
+    assert 'error' not in line['srcnn_train_ms'] and line['srcnn_train_ms']['train_ms'] > 0, line['srcnn_train_ms']
     assert line['subpixel']['bound'] == 'hbm' and 0.3 < line['subpixel']['frac'] < 1.0
     assert 'error' not in line['enet_pat'], line['enet_pat']
     assert line['enet_pat']['tiles_512']['g_trainer_ms'] > 0

@@ -391,3 +391,92 @@ def test_enet_datasets_image_batches(tmp_path):
         np.testing.assert_array_equal(bq[i].cpu().numpy(), O.u8_to_pm1(b8))
     sd2, _, _ = next(it)
     assert tuple(sd2.shape) == (5, 32, 32, 3)
+
+
+# ---- round 4: Adam with its state in device memory; whole train steps replayed as HIP graphs ----------------------------
+def test_adam_device_state_matches_host_argument_path():
+    """srx_adam_tf_step_dev (step count and learning rate in device memory, lr_t evaluated on the device in double
+    precision) against srx_adam_tf_step (lr_t evaluated by the host, a kernel argument) and the float64 oracle: 12 steps,
+    a learning-rate change and a step count set from outside on the way."""
+    from ml_super_resolution_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    n = 10007                                                   # (not a multiple of 4: the scalar tail runs)
+    w0 = torch.randn(n + 1, device='cuda', generator=g)[:n].clone()
+    wa, wb = w0.clone(), w0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device='cuda') for _ in range(4))
+    st = ops.adam_state('cuda', t=0, lr=1e-3)
+    wo, mo, vo = w0.double().cpu().numpy(), np.zeros(n), np.zeros(n)
+    lr, t = 1e-3, 0
+    for i in range(12):
+        if i == 5:
+            lr = 2.5e-4
+            ops.adam_state_set(st, lr=lr)
+        if i == 8:
+            t = 999                                             # as after a checkpoint load
+            ops.adam_state_set(st, t=t)
+        grad = torch.randn(n, device='cuda', generator=g)
+        t += 1
+        ops.adam_tf_step(wa, grad, ma, va, lr, t, 0.5, 0.9, 1e-8)
+        ops.adam_tf_step_dev(wb, grad, mb, vb, st, 0.5, 0.9, 1e-8)
+        wo, mo, vo = O.adam_tf(wo, grad.double().cpu().numpy(), mo, vo, lr, t, 0.5, 0.9, 1e-8)
+        got_t, got_lr, got_lr_t = ops.adam_state_get(st)
+        assert got_t == t and abs(got_lr - lr) < 1e-12 * 1e6
+        ref_lr_t = lr * np.sqrt(1 - float(np.float32(0.9)) ** t) / (1 - 0.5 ** t)     # (the betas cross the C ABI as floats)
+        assert abs(got_lr_t - ref_lr_t) <= 1e-7 * ref_lr_t
+    assert torch.equal(ma, mb) and torch.equal(va, vb)          # (no lr_t in the slots)
+    # the weights: the same float lr_t unless the device's double-precision pow rounds the other way once in 2^29 times
+    assert (wa - wb).abs().max().item() <= 1e-7 * wa.abs().max().item()
+    close(wb, wo, 1e-5)
+
+
+@pytest.mark.parametrize('net', ['espcn', 'srcnn'])
+def test_train_step_graph_replay_equals_eager_launches(net):
+    """ESPCN / SRCNN train steps replayed as one HIP graph per batch shape (engine.ConvStack.train_step_replay) against
+    the same steps as eager launches: weights, Adam slots, gradients and the loss bit-identical after 10 steps; a fed
+    learning rate that changes on the way (ESPCN's schedule, espcn/espcn/experiment_train.py:100-113), a batch of another
+    shape in between (buffers are replaced: the captured step is dropped and rebuilt) and a step count set from outside."""
+    from ml_super_resolution_amd.espcn import model_espcn
+    from ml_super_resolution_amd.srcnn import srcnn
+    g = torch.Generator(device='cuda').manual_seed(11)
+    if net == 'espcn':
+        ma, mb = model_espcn.EspcnModel(3, device='cuda', seed=5), model_espcn.EspcnModel(3, device='cuda', seed=5)
+        xs = [torch.rand((64, 17, 17, 3), device='cuda', generator=g) * 2 - 1 for _ in range(3)]
+        ts = [torch.rand((64, 17, 17, 27), device='cuda', generator=g) * 2 - 1 for _ in range(3)]
+        x2, t2 = torch.rand((8, 9, 13, 3), device='cuda', generator=g), torch.rand((8, 9, 13, 27), device='cuda', generator=g)
+        step = lambda m, x, t, lr: m.train_step(x, t, lr)
+    else:
+        fl = srcnn._flags().parse_args(['--train', '--crop-image-size', '33'])
+        srcnn.sanity_check(fl)
+        ma, mb = srcnn.SrcnnModel(fl, device='cuda', seed=5), srcnn.SrcnnModel(fl, device='cuda', seed=5)
+        for m in (ma, mb):
+            for i in range(3):
+                m.stack.kernel(i).mul_(60.0)                  # O(1) activations instead of the reference's sigma 1e-3
+        xs = [torch.rand((16, 33, 33, 3), device='cuda', generator=g) * 2 - 1 for _ in range(3)]
+        ts = [torch.rand((16, 21, 21, 3), device='cuda', generator=g) * 2 - 1 for _ in range(3)]
+        x2, t2 = torch.rand((2, 40, 37, 3), device='cuda', generator=g), torch.rand((2, 28, 25, 3), device='cuda', generator=g)
+        step = lambda m, x, t, lr: m.train_step(x, t)
+    assert torch.equal(ma.stack.params, mb.stack.params)
+    ma.stack.use_step_graph = False
+    assert mb.stack.use_step_graph
+    losses = []
+    for i in range(14):
+        lr = 1e-3 if i < 6 else 3e-4
+        if i == 9:
+            x, t = x2, t2                                     # another batch shape in between
+        else:
+            x, t = xs[i % 3], ts[i % 3]
+        if i == 11:
+            ma.stack.global_step = mb.stack.global_step = 5000
+        la = step(ma, x, t, lr).clone()
+        lb = step(mb, x, t, lr).clone()
+        losses.append((la, lb))
+        assert ma.stack.global_step == mb.stack.global_step
+    replayed = [k for k, e in mb.stack._step_graphs.items() if e['graph'] is not None]
+    assert replayed, 'no step was replayed from a graph'
+    assert not any(e['graph'] is not None for e in ma.stack._step_graphs.values())
+    for la, lb in losses:
+        assert torch.equal(la, lb)
+    for name in ('params', 'grads', 'opt_m', 'opt_v'):
+        assert torch.equal(getattr(ma.stack, name), getattr(mb.stack, name)), name
+    from ml_super_resolution_amd import ops
+    assert ops.adam_state_get(ma.stack._adam_state)[0] == ops.adam_state_get(mb.stack._adam_state)[0] == ma.stack.global_step == 5003

@@ -533,3 +533,29 @@ def test_stride2_argument_errors(ops):
     d = ops.conv_desc(x.shape, w.shape, 'same', stride=2)
     rc = _lib.lib().srx_conv2d_bwd_data(ctypes.byref(d), None, None, None, 0, None, None, 0, None)
     assert rc != 0
+
+
+@pytest.mark.parametrize('shape', [(1, 300, 260, 'VALID', 'tanh'), (2, 190, 171, 'SAME', None), (1, 247, 250, 'VALID', 'relu'), (3, 160, 130, 'SAME', 'tanh')],
+                         ids=['1x300x260_valid', '2x190x171_same', '1x247x250_valid', '3x160x130_same'])
+def test_conv_5x5_32_to_3_kw_rows_route_vs_oracle(shape, ops):
+    """SRCNN's reconstruction layer (srcnn/srcnn.py:122-130: 5x5 32 -> 3, tanh) on inputs of more than 60,000 output pixels
+    runs conv_kwrows_kernel: (kw, co) pairs as the MFMA's rows, the kw partial sums added through LDS.  Against the
+    oracle: VALID (the reference's geometry) and SAME (zero padding inside the staged tile), strips narrower than 60
+    columns, tiles shorter than 8 rows, several images; and against the 16-output-channel MFMA kernel the smaller
+    problems stay on (same products, another summation order: agreement to rounding)."""
+    N, H, W, pad, act = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, 32)).astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(25 * 32), (5, 5, 32, 3)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (3,)).astype(np.float32)
+    ref = O.c_conv2d_fwd(x, w, b, pad, act)
+    assert ref.shape[0] * ref.shape[1] * ref.shape[2] > 60000
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    close(y, ref)
+    assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, pad, act))
+    # one image of the batch alone is below the threshold: the MFMA kernel
+    y1 = ops.conv2d_fwd(xd[:1, :120].contiguous(), wd, bd, pad, act)
+    close(y1, O.c_conv2d_fwd(x[:1, :120], w, b, pad, act))
+    rows = y1.shape[1] - (0 if pad == 'VALID' else 2)       # (SAME: the cut image's last rows see other padding)
+    assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
