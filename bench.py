@@ -349,6 +349,10 @@ def extras(model, dev, stream, x64, y64, px):
         ehr = torch.rand((eb, 17, 17, 27), device=dev) * 2 - 1
         for _ in range(6):
             e3.train_step(elr, ehr, 1e-3)
+        st_in = e3.stack.static_step_inputs(elr.shape, ehr.shape)     # batches written straight into the captured step's inputs
+        if st_in is not None:
+            st_in[0].copy_(elr); st_in[1].copy_(ehr)
+            elr, ehr = st_in
         us_g = hip_event_time_ms(lambda: e3.train_step(elr, ehr, 1e-3), 200, stream) * 1e3
         e3.stack.use_step_graph = False
         for _ in range(3):

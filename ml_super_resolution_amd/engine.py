@@ -340,7 +340,7 @@ class ConvStack(object):
             else:
                 self.momentum_clip_step(lr, momentum, gradient_cap)
             return self.loss
-        if not self.use_step_graph or self.grad_hook is not None or self.device.type != 'cuda' or self.overlap_wgrad or self.overlap_reduce:
+        if not self.use_step_graph or self.grad_hook is not None or self.device.type != 'cuda' or self.overlap_reduce:
             return eager(x, target)
         opt_key = (float(beta1), float(beta2), float(eps)) if momentum is None else ('momentum', float(lr), float(momentum), float(gradient_cap))
         key = (tuple(x.shape), tuple(target.shape)) + opt_key
@@ -381,6 +381,15 @@ class ConvStack(object):
         if momentum is None:
             self._state_t += 1
         return self.loss
+
+    def static_step_inputs(self, x_shape, target_shape):
+        """The input / target tensors a captured train step of these shapes reads (None before it exists): a training loop
+        that writes its batches straight into them (the host-to-device copy it makes anyway) and passes them to
+        train_step_replay replays without the device-side copies."""
+        for key, ent in self._step_graphs.items():
+            if ent.get('graph') is not None and key[0] == tuple(x_shape) and key[1] == tuple(target_shape):
+                return ent['x'], ent['t']
+        return None
 
     def momentum_clip_step(self, lr, momentum=0.9, gradient_cap=0.01):
         """model_vdsr.py:158-184: clip every gradient element to +-gradient_cap/lr, then Momentum."""

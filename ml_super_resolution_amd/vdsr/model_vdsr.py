@@ -9,6 +9,8 @@ The values are `graph.Tensor` handles to be fetched with `graph.Session().run(..
 the reference fetches `tf.Tensor`s; `model['_model']` is the eager object for callers that keep
 their tensors on the GPU (bench.py, the data-parallel trainer).
 """
+import os
+
 import torch
 
 from .. import graph
@@ -34,6 +36,7 @@ class VdsrModel(object):
         # l2_regularizer(0.0001) on every kernel (model_vdsr.py:34,70,93); residual sr = sd + conv.N (:104)
         self.stack = ConvStack(layer_specs(num_layers), device=device, residual=True, weight_decay=1e-4)
         self.learning_rate = 0.1          # tf.get_variable('learning_rate', init 0.1) (model_vdsr.py:136-141)
+        self.step_graph = os.environ.get('SRX_VDSR_STEP_GRAPH', '0') == '1'
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
         for i in range(num_layers):
             xavier_uniform_(self.stack.kernel(i), gen)      # xavier_initializer (:27); biases zero
@@ -48,11 +51,21 @@ class VdsrModel(object):
         """One `session.run(trainer)`: forward, loss (MSE + L2), backward, optimizer, step += 1.
         Returns the device scalar holding the loss of THIS forward (pre-update weights)."""
         lr = self.learning_rate if learning_rate is None else learning_rate
-        # one replayed HIP graph per batch shape (engine.ConvStack.train_step_replay; eager launches under data parallelism):
-        # ~100 launches per step, at the reference's default batches their host-side issue would otherwise bound the step
+        if self.step_graph:
+            # SRX_VDSR_STEP_GRAPH=1: the whole step as one replayed HIP graph per batch shape (engine.ConvStack.train_step_replay).
+            # Off by default: measured on MI355X the step is bound by the GPU side of its ~100 dependent launches at every
+            # batch size (batch 16 / 64 / 256: 1.94 / 4.56 / 14.09 ms replayed against 1.91 / 4.53 / 13.97 ms eager), so the
+            # replay saves nothing and costs two input copies.
+            if self.use_adam:
+                return self.stack.train_step_replay(sd_images, hd_images, lr)                          # model_vdsr.py:145-148
+            return self.stack.train_step_replay(sd_images, hd_images, lr, momentum=0.9, gradient_cap=0.01)   # model_vdsr.py:158-184
+        self.stack.forward(sd_images, keep=True)
+        loss = self.stack.loss_and_backward(hd_images)
         if self.use_adam:
-            return self.stack.train_step_replay(sd_images, hd_images, lr)                          # model_vdsr.py:145-148
-        return self.stack.train_step_replay(sd_images, hd_images, lr, momentum=0.9, gradient_cap=0.01)   # model_vdsr.py:158-184
+            self.stack.adam_step(lr)                                   # model_vdsr.py:145-148
+        else:
+            self.stack.momentum_clip_step(lr, 0.9, gradient_cap=0.01)  # model_vdsr.py:158-184
+        return loss
 
     def taps(self):
         """conv.i / relu.i are the same post-ReLU tensor (tf.layers.conv2d already applied the
