@@ -454,7 +454,7 @@ def vdsr_recipe(dev, stream, batch=64, size=128):
             lms = hip_event_time_ms(fn, 10, stream)
             ltf = MID_LAYER_FLOP_PER_PX * px / (lms * 1e-3) / 1e12
             out[name] = {'launch_ms': round(lms, 4), 'achieved': round(ltf, 2), 'frac': round(ltf / PEAK_FP32_MFMA_TFLOPS, 4)}
-        out['kernels'] = 'conv_pipe_strip_kernel (fwd, dgrad + ReluGrad), wgrad_pipe_strip_kernel + reduce_partials_kernel: 3x3 64->64 at %dx%dx%d, TFLOP/s of %g peak' % (batch, size, size, PEAK_FP32_MFMA_TFLOPS)
+        out['kernels'] = 'conv_pipe_strip_kernel (fwd, dgrad + ReluGrad), wgrad_rows_strip_kernel + reduce_partials_kernel: 3x3 64->64 at %dx%dx%d, TFLOP/s of %g peak' % (batch, size, size, PEAK_FP32_MFMA_TFLOPS)
         return out
     except Exception as exc:             # a secondary number must never take the primary line down
         return {'error': repr(exc)}
