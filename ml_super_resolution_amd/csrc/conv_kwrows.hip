@@ -14,13 +14,27 @@
 // window of the one-launch SRCNN kernel (whose tests demand bit-equality with the per-layer MFMA launches).
 //
 // A persistent workgroup (one per CU, 128 KiB of LDS) owns tiles of 8 output rows x 60 output columns: the (8 + KH - 1) x 64
-// input pixels are staged once (stage_tile: zero padding by selects), each wave then computes whole output rows: 4 blocks
-// of 16 input columns x 40 MFMAs, P through LDS, epilogue by one lane per output pixel (12-byte stores).
+// input pixels are staged once (bounds-checked buffer loads: zero padding for free; fetched into registers one tile
+// ahead), each wave then computes whole output rows: 4 blocks of 16 input columns x 40 MFMAs, P through LDS, epilogue by
+// one lane per output pixel (12-byte stores).
 #include "launchers.h"
 namespace srx {
 
-template <int KH, int KW, int CIN, int CO>
-__global__ __launch_bounds__(256, 1) void conv_kwrows_kernel(const ConvArgs a, int units_total, int tiles_per_col) {
+// 8 MFMAs of one fragment pair, pinned: two independent accumulator chains, alternating.  (Leading s_nop: an operand may have
+// been written by a VALU instruction right before the block -- the accumulators' zero initialisation.)
+__device__ __forceinline__ void mfma8_kw(f32x4& a0, f32x4& a1, const float (&w)[4], const f32x4 x0, const f32x4 x1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %2, %10, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %3, %11, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %4, %12, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %9, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %5, %13, %1"
+                 : "+v"(a0), "+v"(a1)
+                 : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(x0[0]), "v"(x0[1]), "v"(x0[2]), "v"(x0[3]),
+                   "v"(x1[0]), "v"(x1[1]), "v"(x1[2]), "v"(x1[3]));
+}
+
+template <int KH, int KW, int CIN, int CO, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_kwrows_kernel(const ConvArgs a, int units_total) {
     static_assert(KW * CO <= 16, "the (kw, co) pairs are the 16 rows of the MFMA");
     static_assert(CIN % 16 == 0 && CIN >= 16, "input channels in groups of 16 (one ds_read_b128 per lane and group)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -59,35 +73,74 @@ __global__ __launch_bounds__(256, 1) void conv_kwrows_kernel(const ConvArgs a, i
     // a contiguous range of tiles per workgroup: it walks down a column strip, and the KH - 1 halo rows a tile shares with
     // the one above it were read by the same CU a moment ago (L2 hits)
     const int u0 = (int)(((long)blockIdx.x * units_total) / gridDim.x), u1 = (int)(((long)(blockIdx.x + 1) * units_total) / gridDim.x);
-    for (int u = u0; u < u1; ++u) {
-        // unit -> (image, column strip, tile row), the tile row running fastest
-        const int ti = u % tiles_per_col;
-        const int t2 = u / tiles_per_col;
-        const int tx = t2 % a.NTX, n = t2 / a.NTX;
-        const int h0 = ti * TH, ow0 = tx * TWO;
-        const int th = a.OH - h0 < TH ? a.OH - h0 : TH;
-        const int tw = a.OW - ow0 < TWO ? a.OW - ow0 : TWO;
+    // The NEXT tile's input is fetched into registers while the current one is computed (24 x 16 bytes per thread: the
+    // kernel owns the CU's whole register file) and written to LDS at the top of the next iteration -- one LDS buffer,
+    // the global-memory latency of a tile (~4 of 10 us per tile when it was staged between the barriers) hidden.
+    // Slot s of a tile <-> (row s / 64, column s % 64); out-of-image slots carry an out-of-range offset: the buffer load
+    // returns the zero padding by itself.
+    constexpr int TPP = CIN / 4, PPP = 64 * NW / TPP, NPASS = (TH + KH - 1) * RSW / PPP;
+    static_assert(((TH + KH - 1) * RSW) % PPP == 0, "whole staging passes");
+    const int c4 = tid % TPP, sp = tid / TPP;
+    f32x4 pre[NPASS];
+    // units are the output rows of the strips (a contiguous range per workgroup, balanced to a row); a tile = up to TH of them
+    auto tile_of = [&](int u, int& n, int& h0, int& ow0, int& th, int& tw) {
+        h0 = u % a.OH;
+        const int t2 = u / a.OH;
+        const int tx = t2 % a.NTX;
+        n = t2 / a.NTX;
+        ow0 = tx * TWO;
+        th = a.OH - h0 < TH ? a.OH - h0 : TH;
+        if (u1 - u < th) th = u1 - u;
+        tw = a.OW - ow0 < TWO ? a.OW - ow0 : TWO;
+    };
+    auto fetch = [&](int u) {
+        int n, h0, ow0, th, tw;
+        tile_of(u, n, h0, ow0, th, tw);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + (size_t)n * a.H * a.W * CIN, 0, a.H * a.W * CIN * 4, 0x00020000);
+        const int hin = h0 - a.pad_t, win = ow0 - a.pad_l;
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) {
+            const int sl = sp + j * PPP;
+            const int ih = hin + (sl >> 6), iw = win + (sl & 63);
+            const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & ((sl >> 6) < th + KH - 1);
+            pre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? ((ih * a.W + iw) * CIN + 4 * c4) * 4 : kOobOffset, 0, 0));
+        }
+    };
+    if (u0 < u1) fetch(u0);
+    for (int u = u0; u < u1;) {
+        int n, h0, ow0, th, tw;
+        tile_of(u, n, h0, ow0, th, tw);
+        const int un = u + th;
         lds_barrier();          // every wave is done with the previous tile
-        stage_tile<CIN>(tile, a.x, n, a.H, a.W, a.Cin, h0 - a.pad_t, ow0 - a.pad_l, RSW, 1.0f / (float)RSW, (th + KH - 1) * RSW, tid);
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) *reinterpret_cast<f32x4*>(tile + (sp + j * PPP) * PS + 4 * c4) = pre[j];
         lds_barrier();
-        for (int r = wave; r < th; r += 4) {
+        if (un < u1) fetch(un);
+        for (int r = wave; r < th; r += NW) {
             // ---- P of output row r: NB blocks of 16 input columns, two at a time (two independent MFMA chains)
 #pragma unroll
             for (int b = 0; b < NB; b += 2) {
+                if (16 * b >= tw + KW - 1) continue;        // (a narrow last strip: no input columns there; wave-uniform)
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 const float* px = tile + ((r * RSW + 16 * b + li) * PS + 4 * kq);
+                // software pipeline over the KH * NG fragment pairs: the LDS reads of pair t + 1 are issued before the MFMAs
+                // of pair t (hipcc on its own reuses one register set and exposes the LDS latency every 8 MFMAs: 63 %)
+                constexpr int NT = KH * NG;
+                f32x4 c0 = *reinterpret_cast<const f32x4*>(px), c1 = *reinterpret_cast<const f32x4*>(px + 16 * PS);
 #pragma unroll
-                for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(px + kh * RSW * PS + 16 * g);
-                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(px + kh * RSW * PS + 16 * PS + 16 * g);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kh][g][s], x0[s], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kh][g][s], x1[s], acc1, 0, 0, 0);
-                        }
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 n0 = c0, n1 = c1;
+                    if (t + 1 < NT) {
+                        const int kh1 = (t + 1) / NG, g1 = (t + 1) % NG;
+                        n0 = *reinterpret_cast<const f32x4*>(px + kh1 * RSW * PS + 16 * g1);
+                        n1 = *reinterpret_cast<const f32x4*>(px + kh1 * RSW * PS + 16 * PS + 16 * g1);
                     }
+                    mfma8_kw(acc0, acc1, wa[t / NG][t % NG], c0, c1);
+                    c0 = n0; c1 = n1;
+                }
+                // MFMA results are read by the LDS writes next: software covers the result latency (the MFMAs above are asm)
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
                 // lane (li, kq) holds rows 4 kq .. 4 kq + 3 of input column 16 b + li
                 *reinterpret_cast<f32x4*>(pbuf + (16 * b + li) * PST + 4 * kq) = acc0;
                 *reinterpret_cast<f32x4*>(pbuf + (16 * (b + 1) + li) * PST + 4 * kq) = acc1;
@@ -109,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void conv_kwrows_kernel(const ConvArgs a, i
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads above, before the next row's P overwrites them
         }
+        u = un;
     }
 }
 
@@ -119,10 +173,9 @@ bool launch_conv_kwrows(const ConvKey& k, const ConvArgs& a, long min_pixels, hi
     if ((long)a.N * a.OH * a.OW < min_pixels) return false;
     if ((long)a.H * a.W * a.Cin * 4 >= (1L << 31) - 4096) return false;       // stage_tile's 32-bit in-image offsets
     ConvArgs b = a;
-    constexpr int TH = 8, TWO = 60;
+    constexpr int TH = 8, TWO = 60, kWaves = 8;      // (8 waves: two per SIMD, one's epilogue under the other's MFMAs)
     b.NTX = (a.OW + TWO - 1) / TWO;
-    const int tiles_per_col = (a.OH + TH - 1) / TH;
-    const long units = (long)a.N * b.NTX * tiles_per_col;
+    const long units = (long)a.N * b.NTX * a.OH;           // strip rows
     if (units >= (1L << 31)) return false;
     int cus = 256;
     {
@@ -130,16 +183,17 @@ bool launch_conv_kwrows(const ConvKey& k, const ConvArgs& a, long min_pixels, hi
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else (void)hipGetLastError();
     }
-    const int grid = (int)(units < cus ? units : cus);
-    const size_t lds = ((size_t)(TH + 4) * 64 * Lds<32>::PS + 4 * 64 * 20) * sizeof(float);
+    const long tiles = (units + TH - 1) / TH;
+    const int grid = (int)(tiles < cus ? tiles : cus);
+    const size_t lds = ((size_t)(TH + 4) * 64 * Lds<32>::PS + kWaves * 64 * 20) * sizeof(float);
     // (> 64 KiB of dynamic LDS needs the attribute: raised once per host thread, outside any stream capture of later launches)
     static thread_local bool configured = false;
     if (!configured) {
-        *err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kwrows_kernel<5, 5, 32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        *err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kwrows_kernel<5, 5, 32, 3, kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (*err != hipSuccess) return true;
         configured = true;
     }
-    hipLaunchKernelGGL((conv_kwrows_kernel<5, 5, 32, 3>), dim3(grid), dim3(256), lds, s, b, (int)units, tiles_per_col);
+    hipLaunchKernelGGL((conv_kwrows_kernel<5, 5, 32, 3, kWaves>), dim3(grid), dim3(64 * kWaves), lds, s, b, (int)units);
     *err = hipGetLastError();
     return true;
 }
