@@ -827,6 +827,16 @@ hipError_t launch_l2(const float* w, const float* mask, size_t n, float scale, f
 // ---------------------------------------------------------------------------------------------
 // optimizers (flat buffers)
 // ---------------------------------------------------------------------------------------------
+// One element of the update, shared by both Adam kernels below so that they round identically (left to the compiler, the
+// two kernels contracted `b1 * m + ob1 * g` into different fused multiply-adds: slots one ulp apart whenever b1 * m is inexact
+// -- found by scripts/fuzz_round4.py).  m = b1 m + (1 - b1) g and v = b2 v + (1 - b2) g^2, the smaller product rounded first.
+__device__ __forceinline__ void adam_elem(float& w, float g, float& m, float& v, float lr_t, float b1, float b2, float ob1,
+                                          float ob2, float eps) {
+    m = fmaf(b1, m, ob1 * g);
+    v = fmaf(b2, v, ob2 * (g * g));
+    w -= lr_t * m / (sqrtf(v) + eps);
+}
+
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v, size_t n,
                                                       float lr_t, float b1, float b2, float eps, float gs) {
@@ -839,9 +849,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
         f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            mv[e] = b1 * mv[e] + ob1 * gv[e];
-            vv[e] = b2 * vv[e] + ob2 * gv[e] * gv[e];
-            wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+            float me = mv[e], ve = vv[e], we = wv[e];       // (element references of an ext-vector miscompile under bit casts: copies)
+            adam_elem(we, gv[e], me, ve, lr_t, b1, b2, ob1, ob2, eps);
+            mv[e] = me; vv[e] = ve; wv[e] = we;
         }
         reinterpret_cast<f32x4*>(m)[i] = mv;
         reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -849,12 +859,11 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
     }
     if (blockIdx.x == 0) {
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
-            const float gi = g[i] * gs;
-            const float mi = b1 * m[i] + ob1 * gi;
-            const float vi = b2 * v[i] + ob2 * gi * gi;
+            float mi = m[i], vi = v[i], wi = w[i];
+            adam_elem(wi, g[i] * gs, mi, vi, lr_t, b1, b2, ob1, ob2, eps);
             m[i] = mi;
             v[i] = vi;
-            w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+            w[i] = wi;
         }
     }
 }
@@ -889,9 +898,9 @@ __global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ w,
         f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            mv[e] = b1 * mv[e] + ob1 * gv[e];
-            vv[e] = b2 * vv[e] + ob2 * gv[e] * gv[e];
-            wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+            float me = mv[e], ve = vv[e], we = wv[e];       // (element references of an ext-vector miscompile under bit casts: copies)
+            adam_elem(we, gv[e], me, ve, lr_t, b1, b2, ob1, ob2, eps);
+            mv[e] = me; vv[e] = ve; wv[e] = we;
         }
         reinterpret_cast<f32x4*>(m)[i] = mv;
         reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -899,12 +908,11 @@ __global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ w,
     }
     if (blockIdx.x == 0) {
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
-            const float gi = g[i] * gs;
-            const float mi = b1 * m[i] + ob1 * gi;
-            const float vi = b2 * v[i] + ob2 * gi * gi;
+            float mi = m[i], vi = v[i], wi = w[i];
+            adam_elem(wi, g[i] * gs, mi, vi, lr_t, b1, b2, ob1, ob2, eps);
             m[i] = mi;
             v[i] = vi;
-            w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+            w[i] = wi;
         }
     }
     __syncthreads();

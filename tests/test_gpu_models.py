@@ -425,7 +425,7 @@ def test_adam_device_state_matches_host_argument_path():
         assert abs(got_lr_t - ref_lr_t) <= 1e-7 * ref_lr_t
     assert torch.equal(ma, mb) and torch.equal(va, vb)          # (no lr_t in the slots)
     # the weights: the same float lr_t unless the device's double-precision pow rounds the other way once in 2^29 times
-    assert (wa - wb).abs().max().item() <= 1e-7 * wa.abs().max().item()
+    assert (wa - wb).abs().max().item() <= 2e-7 * wa.abs().max().item()
     close(wb, wo, 1e-5)
 
 
