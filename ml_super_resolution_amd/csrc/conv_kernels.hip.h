@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace srx {
 
@@ -2578,6 +2579,303 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_strip_kernel(const WgradArg
             for (int k = 0; k < QW; ++k) { xw[k] += back; SRX_PIN(xw[k]); }
         }
         stage_tile_scalar<CINP, 6, true, true>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        lds_barrier();
+        cur_buf ^= 1;
+        u = un_;
+        t_end += SRX_STAMP() - ts_e;
+    }
+#undef SRX_TAKE_OVER_B
+#ifdef SRX_TRACE
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        tr[0] = t_begin; tr[1] = SRX_STAMP(); tr[2] = t_loop; tr[3] = t_end; tr[4] = 0;
+    }
+#endif
+
+    // MFMA results are read by VALU / stores next
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 64 * q + 4 * (4 * kq + r) + g;
+                const int tap = R / CINP, ci = R % CINP;
+                if (R < ROWS && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (qpart == 0 && kq == 0 && co_ok) pw[(size_t)TAPS * a.Cin * a.Cout + co] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad on full-width tiles, EXACT rows, for image widths OWC = 4 SPR + 1 (41-pixel VDSR patches: SPR = 10).  The padded walk
+// of wgrad_pipe_kernel pays, per 36-MFMA step, a lane-offset table lookup (2 VALU + 1 LDS read) and a dpre cursor (7 SALU), and
+// one fake position in 42.  Here a unit of THC = 3 rows is ONE straight-line window of 3 SPR + 1 = 31 steps over real pixels:
+//   * THC x SPR "row steps": step (row r, j) takes columns 4 j .. 4 j + 3 of row r -- x fragments at ds_read immediates
+//     (r RS + 4 j), the dpre operand at a per-lane base (3 registers) + immediate + the row as scalar offset;
+//   * ONE "column step": the lane groups take the LAST column of rows 0 .. 3 (lane group kq: row kq; row 3 lies beyond a
+//     3-row unit's buffer resource and reads 0) -- a second per-lane base for the x fragments (+ kq (RS - 1) slots) and one
+//     lane offset for dpre.
+// Every address of the window is a compile-time constant; rows past a short unit lie beyond the unit's resource (-> 0), so
+// there is one body and no branch but the unit loop's.  (Units of 4 rows -- 41 steps, no idle lane group in the column step --
+// leave a ONE-row unit at the end of a 41-row image: as a full window that costs 451 steps per image against 434 here and
+// now; as a short second body, chosen before or inside the window, it made hipcc copy in-flight AGPRs at the merge /
+// spill the 41 dpre operands -- both built, both rejected by `make check`.)  41 rows = 13 units of 3 + one of 2: 14 x 31 =
+// 434 steps, the padded walk's count; the gain is the per-step work.  Staging (15 passes: loads in steps 0..14, LDS writes
+// in steps 16..30), double buffering, AGPR parking and the hand-counted waits as in wgrad_pipe_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int IMM>
+__device__ __forceinline__ float dpre_fire_imm(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    float b;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=&a"(b) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
+    return b;
+}
+
+template <int KH, int KW, int CINP, int NCH, int OWC>
+__global__ __launch_bounds__(256, 1) void wgrad_rows_full_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int TAPS = KH * KW;
+    constexpr int ROWS = TAPS * CINP;
+    constexpr int Q = (ROWS + 63) / 64;
+    constexpr int NQP = 4 / NCH;
+    constexpr int QW = (Q + NQP - 1) / NQP;
+    constexpr int TPP = CINP / 4, PPP = 256 / TPP;
+    constexpr int SPR = OWC / 4;             // whole steps per image row
+    constexpr int THC = 3;                   // rows per unit
+    constexpr int RSZ = OWC + 1;             // slots per tile row (one pad column: the host sends SAME 3x3 layers only)
+    constexpr int COUTC = 64;                // output channels (the dpre loads' immediates are multiples of 16 COUTC bytes; host-checked)
+    constexpr int U = THC * SPR + 1;         // steps per window
+    constexpr int JP = (RSZ + PPP - 1) / PPP;
+    constexpr int NPASSES = (THC + KH - 1) * JP;   // staging passes of a full tile
+    constexpr int C0 = (U + 1) / 2;          // first step with an LDS write of the staging (all loads are out by then)
+    constexpr int LA = 2, RN = 3;
+    static_assert(OWC % 4 == 1, "one leftover column per row: the column step takes it for up to four rows at once");
+    static_assert(QW * 16 >= 128 && QW >= 9, "accumulators fill the VGPRs; the dealt-out schedule of a step uses gaps 0..8");
+    static_assert(2 * NPASSES <= U && NPASSES < C0 && C0 + NPASSES <= U, "staging loads in the first half (beside two dpre loads each), LDS writes in the second");
+    static_assert(U == 31, "SRX_TAKE_OVER_B names the 31 registers of a window");
+    static_assert((((THC + 1) * RSZ + 4 * SPR) * PS * 4) < 65536, "ds_read immediates");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, qpart = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int co = cout0 + li;
+    const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;
+    const int c4 = tid % TPP, sp = tid / TPP;
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int buf_bytes = (a.zero_slot + 4) * PS * 4;    // (the host allocates a tile of THC + 3 rows: the column step's idle lane group reads row 3 + KH - 1)
+
+    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+    const int lds_base = (int)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+    int xw[QW];      // LDS byte address of (tile slot kq, the lane's tap / channels) in the running buffer
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        int R = 64 * q + 4 * li;
+        if (q >= Q || R >= ROWS) R = 0;
+        const int tap = R / CINP, ci = R % CINP;
+        xw[k] = lds_base + ((kq + (tap / KW) * RSZ + (tap % KW)) * PS + ci) * 4;
+    }
+    const int dX = kq * (RSZ - 1) * PS * 4;       // column step: lane group kq reads row kq instead of column kq
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 2 * buf_bytes / 16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
+    }
+    const int voff_lane = tid * 16;
+    const int wl_lane = (sp * PS + 4 * c4) * 4;
+    StageGeo SG;
+    SG.JP1 = __builtin_amdgcn_readfirstlane(JP - 1);
+    SG.rowfix_g = __builtin_amdgcn_readfirstlane((a.W - JP * PPP) * CINP * 4);
+    SG.rowfix_l = __builtin_amdgcn_readfirstlane((RSZ - JP * PPP) * PS * 4);
+    SG.m_first = uniform64(__ballot(sp >= a.pad_l));
+    SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < RSZ));
+    SG.m_row = SG.m_last; SG.m_mid = ~0ull;
+    // dpre addressing: a unit's pixels are contiguous (full-width rows); lane part of a row step = column 4 j + kq
+    const int colb = 16 * COUTC;                                        // bytes from one step's first column to the next
+    const int lane_b = (kq * COUTC + co_c) * 4;
+    const int vb0 = lane_b, vb1 = lane_b + 4 * colb, vb2 = lane_b + 8 * colb;      // + (j % 4) colb as the immediate (< 4096)
+    const int vX = ((kq * OWC + OWC - 1) * COUTC + co_c) * 4;           // column step: last column of row kq
+    const int rowb = __builtin_amdgcn_readfirstlane(OWC * COUTC * 4);
+    const int srow1 = rowb, srow2 = __builtin_amdgcn_readfirstlane(2 * rowb);
+
+    f32x4 acc[QW][4];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[k][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+
+    auto tile_of = [&](int uu_, int& n, int& h, int& th) {
+        h = uu_ % a.OH;
+        n = uu_ / a.OH;
+        th = THC;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - uu_ < th) th = u1 - uu_;
+    };
+    auto stage_setup = [&](StageSeq& qi, StageSeq& qc, int h, int th, int buf, bool active) {
+        const int left = __builtin_amdgcn_readfirstlane(active ? (th + KH - 1) * JP : 0);
+        const int above = (a.pad_t > h) ? (a.pad_t - h) * JP : 0;
+        qi.j = 0; qc.j = 0;
+        qi.off = __builtin_amdgcn_readfirstlane((h - a.pad_t) * a.W * CINP * 4);
+        qc.off = __builtin_amdgcn_readfirstlane(buf * buf_bytes);
+        qi.left = left; qc.left = left;
+        qi.thr = __builtin_amdgcn_readfirstlane(left - above);
+        qc.thr = 0;
+    };
+    auto x_rsrc = [&](int n) {
+        return uniform_rsrc(a.x + ((size_t)n * a.H * a.W - a.pad_l) * CINP, (a.H * a.W + a.pad_l) * CINP * 4);
+    };
+    auto b_rsrc = [&](int n, int h, int th) {
+        return uniform_rsrc(a.dpre + ((size_t)n * a.OH + h) * a.OW * COUTC, th * a.OW * COUTC * 4);
+    };
+
+    float bcur[U], bnext[U];
+    // a unit's first dpre window all at once: ordinary (compiler-visible) loads.  Window position i: rows first (i / SPR,
+    // i % SPR), the column step last.
+    auto dpre_window_now = [&](__amdgpu_buffer_rsrc_t brs) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if (i == U - 1) {
+                bnext[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, vX, 0, 0));
+            } else {
+                const int r = i / SPR, j = i % SPR;
+                const int vb = j < 4 ? vb0 : (j < 8 ? vb1 : vb2);
+                bnext[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, vb + (j % 4) * colb, r * rowb, 0));
+            }
+        }
+    };
+    // (inline asm takes at most 30 operands: the wait names the registers in two statements)
+#define SRX_TAKE_OVER_B()                                                                                          \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0) ; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15"                  \
+                     : "+a"(bnext[0]), "+a"(bnext[1]), "+a"(bnext[2]), "+a"(bnext[3]), "+a"(bnext[4]), "+a"(bnext[5]), \
+                       "+a"(bnext[6]), "+a"(bnext[7]), "+a"(bnext[8]), "+a"(bnext[9]), "+a"(bnext[10]),            \
+                       "+a"(bnext[11]), "+a"(bnext[12]), "+a"(bnext[13]), "+a"(bnext[14]), "+a"(bnext[15]));       \
+        asm volatile("; %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14"                                         \
+                     : "+a"(bnext[16]), "+a"(bnext[17]), "+a"(bnext[18]), "+a"(bnext[19]), "+a"(bnext[20]),        \
+                       "+a"(bnext[21]), "+a"(bnext[22]), "+a"(bnext[23]), "+a"(bnext[24]), "+a"(bnext[25]),        \
+                       "+a"(bnext[26]), "+a"(bnext[27]), "+a"(bnext[28]), "+a"(bnext[29]), "+a"(bnext[30]));       \
+        _Pragma("unroll") for (int j = 0; j < U; ++j)                                                              \
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(bcur[j]) : "a"(bnext[j]));                             \
+    } while (0)
+
+    int u = u0;
+    int n, h, th;
+    tile_of(u, n, h, th);
+    [[maybe_unused]] unsigned long long t_loop = 0, t_end = 0;   // (trace builds)
+    [[maybe_unused]] const unsigned long long t_begin = SRX_STAMP();
+    __syncthreads();
+    {
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h, th, 0, true);
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, x_rsrc(n), voff_lane, wl_lane);
+        dpre_window_now(b_rsrc(n, h, th));
+        lds_barrier();
+        SRX_TAKE_OVER_B();
+    }
+    int cur_buf = 0;
+    while (u < u1) {
+        tile_of(u, n, h, th);
+        const int un_ = u + th;
+        const bool has_next = un_ < u1;
+        int n2 = n, h2 = h, th2 = th;
+        if (has_next) tile_of(un_, n2, h2, th2);
+        StageSeq qi, qc;
+        stage_setup(qi, qc, h2, th2, cur_buf ^ 1, has_next);
+        const __amdgpu_buffer_rsrc_t xrs = x_rsrc(n2);
+        const __amdgpu_buffer_rsrc_t brs_pf = b_rsrc(n2, h2, has_next ? th2 : 0);
+
+        // x fragment of window position i (i == U: the position after the window -- prefetched by the ring, never used)
+        auto xaddr = [&](int k, int i) -> unsigned {
+            if (i == U - 1) return (unsigned)(xw[k] + dX + (OWC - 1) * PS * 4);
+            const int r = i >= U ? THC : i / SPR, j = i >= U ? 0 : i % SPR;
+            return (unsigned)(xw[k] + (r * RSZ + 4 * j) * PS * 4);
+        };
+        auto read_x = [&](int k, int i) -> f32x4 { return *(lds_f32x4*)(uintptr_t)xaddr(k, i); };
+        f32x4 ring[RN];
+#pragma unroll
+        for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
+
+        const unsigned long long ts_l = SRX_STAMP();
+        f32x4 stg[NPASSES];
+        // one step of the window (position i a compile-time constant: hipcc does not unroll a 31 x 9 loop nest of this size by
+        // itself): 9 fragments x 4 MFMAs, and the step's share of the extra work dealt out over the gaps
+        auto step = [&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            const float b = bcur[i];
+            bsum += b;
+            unsigned long long smk = 0, smt = 0;
+            int sso = 0;
+#pragma unroll
+            for (int k = 0; k < QW; ++k) {
+                const int idx = (i * QW + k) % RN;
+                const int kk = k + LA;
+                ring[(idx + LA) % RN] = read_x(kk % QW, i + kk / QW);
+                mfma4_wgrad(acc[k], ring[idx], b);
+                // dpre of the NEXT unit's window positions 2 i (gap 1) and 2 i + 1 (gap 7)
+                if ((k == 1 && 2 * i < U) || (k == 7 && 2 * i + 1 < U)) {
+                    const int p = 2 * i + (k == 7 ? 1 : 0);
+                    if (p == U - 1) {
+                        bnext[p] = dpre_fire_imm<0>(brs_pf, vX, 0);
+                    } else {
+                        const int r = p / SPR, j = p % SPR;
+                        const int vb = j < 4 ? vb0 : (j < 8 ? vb1 : vb2);
+                        const int so = r == 0 ? 0 : (r == 1 ? srow1 : srow2);
+                        switch (j % 4) {
+                            case 0: bnext[p] = dpre_fire_imm<0>(brs_pf, vb, so); break;
+                            case 1: bnext[p] = dpre_fire_imm<16 * COUTC>(brs_pf, vb, so); break;
+                            case 2: bnext[p] = dpre_fire_imm<32 * COUTC>(brs_pf, vb, so); break;
+                            default: bnext[p] = dpre_fire_imm<48 * COUTC>(brs_pf, vb, so); break;
+                        }
+                    }
+                }
+                // one staging pass of the next tile: load in steps 0 .. NPASSES-1, LDS write in steps C0 .. C0+NPASSES-1
+                if constexpr (i < NPASSES) {
+                    if (k == 2) { if (i > 0) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }
+                    if (k == 3) stage_mask_a(qi, SG, smk, smt);
+                    if (k == 4) stage_mask_b(qi, smk, smt, sso);
+                    if (k == 6) stg[i < NPASSES ? i : 0] = stage_fire_a(smk, sso, xrs, voff_lane);
+                }
+                if constexpr (i == NPASSES) { if (k == 2) stage_next<PPP * CINP * 4>(qi, SG.JP1, SG.rowfix_g); }     // (the cursor step of the last pass)
+                if constexpr (i >= C0 && i < C0 + NPASSES) {
+                    constexpr int jj = i - C0;
+                    // memory operations certainly younger than the pass's load: its step's second dpre load, three per later
+                    // staging step, the dpre loads issued after the last staging step
+                    constexpr int after = 1 + 3 * (NPASSES - 1 - jj) + (U - 2 * NPASSES);
+                    if (k == 0) stage_commit_a(after >= 14 ? 14 : (after & ~1), qc, stage_mask_full(qc, SG), wl_lane, stg[jj < NPASSES ? jj : 0]);
+                    if (k == 4) stage_next<PPP * PS * 4>(qc, SG.JP1, SG.rowfix_l);
+                }
+            }
+        };
+#define SRX_ONE_STEP(I) step(std::integral_constant<int, I>{});
+        SRX_ONE_STEP(0) SRX_ONE_STEP(1) SRX_ONE_STEP(2) SRX_ONE_STEP(3) SRX_ONE_STEP(4) SRX_ONE_STEP(5) SRX_ONE_STEP(6) SRX_ONE_STEP(7)
+        SRX_ONE_STEP(8) SRX_ONE_STEP(9) SRX_ONE_STEP(10) SRX_ONE_STEP(11) SRX_ONE_STEP(12) SRX_ONE_STEP(13) SRX_ONE_STEP(14) SRX_ONE_STEP(15)
+        SRX_ONE_STEP(16) SRX_ONE_STEP(17) SRX_ONE_STEP(18) SRX_ONE_STEP(19) SRX_ONE_STEP(20) SRX_ONE_STEP(21) SRX_ONE_STEP(22) SRX_ONE_STEP(23)
+        SRX_ONE_STEP(24) SRX_ONE_STEP(25) SRX_ONE_STEP(26) SRX_ONE_STEP(27) SRX_ONE_STEP(28) SRX_ONE_STEP(29) SRX_ONE_STEP(30)
+#undef SRX_ONE_STEP
+        SRX_TAKE_OVER_B();
+        const unsigned long long ts_e = SRX_STAMP();
+        t_loop += ts_e - ts_l;
+        {
+            const int flip = __builtin_amdgcn_readfirstlane(cur_buf ? -buf_bytes : buf_bytes);
+#pragma unroll
+            for (int k = 0; k < QW; ++k) { xw[k] += flip; SRX_PIN(xw[k]); }
+        }
+        stage_tile_scalar<CINP, 6>(qi, qc, SG, xrs, voff_lane, wl_lane);
         lds_barrier();
         cur_buf ^= 1;
         u = un_;

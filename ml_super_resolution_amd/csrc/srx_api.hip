@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_nt, kwrows_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_nt, kwrows_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -40,6 +40,7 @@ Knobs read_knobs() {
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
     k.wgrad_pipe_strip = env_int("SRX_WGRAD_PIPE_STRIP", 1);   // 0: column-strip filter gradients on the two-workgroup kernel (A/B)
     k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 60000);   // 5x5 32->3 on conv_kwrows_kernel from this many output pixels (negative: never)
+    k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_nt = env_int("SRX_WGRAD_NT", 1);                   // strip filter gradient: dpre loads marked non-temporal (A/B)
     k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
@@ -567,7 +568,17 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     const int wppp = (p.cinp >= 16) ? 256 / (p.cinp / 4) : 256;
     int wgrid = p.grid;
     bool wdone = false;
-    if (use_wpipe && lin_ok && d->Cin == p.cinp && p.RS >= wppp && 2 * lin_lds <= 160 * 1024) {
+    // 41-pixel rows (the VDSR patch of BASELINE's metric): exact rows, one 31-step window per 3-row unit (wgrad_rows_full_kernel)
+    if (use_wpipe && knobs().wgrad_rows_full && lin_ok && d->KH == 3 && d->KW == 3 && d->Cin == 64 && d->Cout == 64 && OW == 41 && d->W == 41 &&
+        pl == 1 && pt == 1 && p.RS == 42) {
+        WgradArgs ap = a;
+        ap.TH = 3;                                  // units of 3 rows: one window of 31 steps
+        ap.zero_slot = (3 + 3) * 42 + 2;            // (a tile row more than the unit needs: the column step's idle lane group reads it)
+        wgrid = p.grid < kPipeGrid ? p.grid : kPipeGrid;
+        wdone = launch_wgrad_rows_full(k, ap, wgrid, 2 * (size_t)(ap.zero_slot + 4) * (64 + 4) * 4, s, &err);
+        if (!wdone) wgrid = p.grid;
+    }
+    if (!wdone && use_wpipe && lin_ok && d->Cin == p.cinp && p.RS >= wppp && 2 * lin_lds <= 160 * 1024) {
         // Its step loop runs whole windows of 14 steps (4 positions each), padding a unit's last window with
         // zero-operand steps: pick the tile height that wastes the fewest (41-wide rows: 4 rows = 168 positions =
         // 3 windows exactly), and make sure the padded walk stays inside the tile buffer.

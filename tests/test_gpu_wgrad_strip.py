@@ -105,3 +105,46 @@ def test_vdsr_recipe_size_filter_gradient_properties(ops):
     dws, dbs = ops.conv2d_bwd_filter(x[30:32], dpre[30:32], (3, 3, 64, 64), 'same')
     close(dws, dw_ref)
     close(dbs, db_ref)
+
+
+# ---- 41-pixel rows (the VDSR patch of BASELINE's metric) on full-width tiles: wgrad_rows_full_kernel -----------------------
+ROWS41_SHAPES = [(1, 41), (3, 41), (1, 1), (1, 2), (2, 3), (1, 4), (5, 5), (2, 40), (7, 13), (37, 41), (300, 6), (1, 200)]
+
+
+@pytest.mark.parametrize('shape', ROWS41_SHAPES, ids=['%dx%dx41' % s for s in ROWS41_SHAPES])
+def test_rows41_filter_gradient_vs_oracle_and_vs_padded_walk(shape, ops):
+    """3x3 64 -> 64 SAME on 41-pixel rows: units of 3 rows, one 31-step window each (30 row steps of 4 real pixels + one
+    column step taking the last column of the unit's rows), against the float64 oracle and beside the padded-position walk
+    (wgrad_pipe_kernel, srx_set_wgrad_path(2) with SRX_WGRAD_ROWS_FULL=0 is not reachable at run time: path 1, the
+    two-workgroup walk, is the comparison).  Heights of 1, 2 (short units only), 3, 4, 5 (one full + one short unit), 40, 41, 200;
+    batches whose workgroup ranges cut images; many small images."""
+    N, H = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('rows41',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, 41, 64)).astype(np.float32)
+    dpre = rng.normal(0, 1, (N, H, 41, 64)).astype(np.float32)
+    dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (3, 3), 'SAME')
+    xd, dd = dev(x), dev(dpre)
+    dw, db = ops.conv2d_bwd_filter(xd, dd, (3, 3, 64, 64), 'same')
+    close(dw, dw_ref)
+    close(db, db_ref)
+    dw2, db2 = ops.conv2d_bwd_filter(xd, dd, (3, 3, 64, 64), 'same')
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw1, db1 = _with_wgrad_path(1, lambda: ops.conv2d_bwd_filter(xd, dd, (3, 3, 64, 64), 'same'))
+    close(dw1, dw_ref)
+    assert (dw1.double() - dw.double()).abs().max().item() <= 2e-6 * max(dw.abs().max().item(), 1e-30)
+
+
+def test_rows41_exact_integer_sums(ops):
+    """x = 1, dpre = 1 on 41-pixel rows: every tap's gradient is the number of valid (pixel, tap) pairs -- the column step and
+    the short last unit (41 = 13 x 3 + 2) must count every pixel exactly once."""
+    N, H, W = 3, 41, 41
+    xd = torch.ones((N, H, W, 64), device='cuda')
+    dd = torch.ones((N, H, W, 64), device='cuda')
+    dw, db = ops.conv2d_bwd_filter(xd, dd, (3, 3, 64, 64), 'same')
+    counts = np.array([[(H - abs(kh - 1)) * (W - abs(kw - 1)) for kw in range(3)] for kh in range(3)], np.float64) * N
+    np.testing.assert_array_equal(dw.cpu().numpy(), np.broadcast_to(counts[:, :, None, None], (3, 3, 64, 64)))
+    np.testing.assert_array_equal(db.cpu().numpy(), np.full((64,), N * H * W, np.float32))
+    # a position-dependent dpre: channel-wise sums of an integer ramp
+    ramp = torch.arange(N * H * W, device='cuda', dtype=torch.float32).remainder(7).view(N, H, W, 1).expand(N, H, W, 64).contiguous()
+    _, db2 = ops.conv2d_bwd_filter(xd, ramp, (3, 3, 64, 64), 'same')
+    assert torch.equal(db2, ramp.sum(dim=(0, 1, 2)))
