@@ -26,6 +26,8 @@ bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hi
 bool launch_wgrad_lin(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_lin_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_pipe(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
+bool launch_wgrad_kwcols(const ConvKey& k, const WgradArgs& a, int max_partials, long min_pixels, int* n_partials, hipStream_t s, hipError_t* err);
+bool launch_wgrad_1x1(const ConvKey& k, const WgradArgs& a, int max_partials, int* n_partials, hipStream_t s, hipError_t* err);
 bool launch_wgrad_rows_full(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_rows_strip(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, bool nt, hipStream_t s, hipError_t* err);
 bool launch_wgrad_lin_pairs(const ConvKey& k, const WgradPairs& q, int grid, int pairs, bool strips, size_t lds, hipStream_t s, hipError_t* err);

@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_nt, kwrows_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_nt, kwrows_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -41,6 +41,7 @@ Knobs read_knobs() {
     k.wgrad_pipe_strip = env_int("SRX_WGRAD_PIPE_STRIP", 1);   // 0: column-strip filter gradients on the two-workgroup kernel (A/B)
     k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 60000);   // 5x5 32->3 on conv_kwrows_kernel from this many output pixels (negative: never)
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
+    k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
     k.wgrad_nt = env_int("SRX_WGRAD_NT", 1);                   // strip filter gradient: dpre loads marked non-temporal (A/B)
     k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
@@ -568,8 +569,19 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     const int wppp = (p.cinp >= 16) ? 256 / (p.cinp / 4) : 256;
     int wgrid = p.grid;
     bool wdone = false;
+    // 1x1 layers (SRCNN 64 -> 32, EnhanceNet's residual blocks 64 -> 64): a streaming GEMM over the pixels, no LDS tile
+    if (knobs().wgrad_1x1 && wpath >= 1 && !s2) {
+        int n1 = 0;
+        if (launch_wgrad_1x1(k, a, p.grid, &n1, s, &err)) { wdone = true; wgrid = n1; }
+    }
+    // SRCNN's 5x5 32 -> 3 layer on large inputs: (kw, co) pairs as the MFMA's columns (conv_kwrows.hip), from the same size on as
+    // the forward route
+    if (!wdone && knobs().kwrows_min_pixels >= 0 && wpath >= 1 && !s2) {
+        int n1 = 0;
+        if (launch_wgrad_kwcols(k, a, p.grid, knobs().kwrows_min_pixels, &n1, s, &err)) { wdone = true; wgrid = n1; }
+    }
     // 41-pixel rows (the VDSR patch of BASELINE's metric): exact rows, one 31-step window per 3-row unit (wgrad_rows_full_kernel)
-    if (use_wpipe && knobs().wgrad_rows_full && lin_ok && d->KH == 3 && d->KW == 3 && d->Cin == 64 && d->Cout == 64 && OW == 41 && d->W == 41 &&
+    if (!wdone && use_wpipe && knobs().wgrad_rows_full && lin_ok && d->KH == 3 && d->KW == 3 && d->Cin == 64 && d->Cout == 64 && OW == 41 && d->W == 41 &&
         pl == 1 && pt == 1 && p.RS == 42) {
         WgradArgs ap = a;
         ap.TH = 3;                                  // units of 3 rows: one window of 31 steps

@@ -559,3 +559,68 @@ def test_conv_5x5_32_to_3_kw_rows_route_vs_oracle(shape, ops):
     close(y1, O.c_conv2d_fwd(x[:1, :120], w, b, pad, act))
     rows = y1.shape[1] - (0 if pad == 'VALID' else 2)       # (SAME: the cut image's last rows see other padding)
     assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1, 64, 32), (1, 3, 7, 64, 64), (2, 25, 25, 64, 32), (3, 33, 41, 32, 32), (1, 235, 235, 64, 32), (5, 64, 67, 64, 64),
+                                   (1, 9, 11, 32, 64), (16, 128, 128, 64, 64)],
+                         ids=lambda s: '%dx%dx%d_%d-%d' % s)
+def test_1x1_filter_gradient_streaming_kernel_vs_oracle(shape, ops):
+    """dW of a 1x1 layer (SRCNN 64 -> 32, srcnn/srcnn.py:111-119; EnhanceNet's residual blocks 64 -> 64) on wgrad_1x1_kernel:
+    pixels streamed straight into MFMA operands, no LDS tile.  Pixel counts that are not multiples of the 4-pixel step, fewer
+    steps than workgroups, one pixel, all four channel pairs; against the oracle, deterministic, and (large case) additive
+    over batch halves."""
+    N, H, W, cin, cout = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('1x1',) + shape).encode()))
+    if N * H * W > 100000:
+        g = torch.Generator(device='cuda').manual_seed(5)
+        xd = torch.rand((N, H, W, cin), device='cuda', generator=g) * 2 - 1
+        dd = torch.randn((N, H, W, cout), device='cuda', generator=g)
+        dw, db = ops.conv2d_bwd_filter(xd, dd, (1, 1, cin, cout), 'same')
+        h = N // 2
+        dwa, dba = ops.conv2d_bwd_filter(xd[:h], dd[:h], (1, 1, cin, cout), 'same')
+        dwb, dbb = ops.conv2d_bwd_filter(xd[h:], dd[h:], (1, 1, cin, cout), 'same')
+        assert (dw.double() - dwa.double() - dwb.double()).abs().max().item() <= 2e-5 * dw.abs().max().item()
+        assert (db.double() - dba.double() - dbb.double()).abs().max().item() <= 2e-5 * db.abs().max().item() + 1e-2
+        ref_w = torch.einsum('nhwi,nhwo->io', xd[:2].double(), dd[:2].double()).cpu().numpy().reshape(1, 1, cin, cout)
+        dws, dbs = ops.conv2d_bwd_filter(xd[:2], dd[:2], (1, 1, cin, cout), 'same')
+        close(dws, ref_w)
+        close(dbs, dd[:2].double().sum(dim=(0, 1, 2)).cpu().numpy())
+        return
+    x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
+    dpre = rng.normal(0, 1, (N, H, W, cout)).astype(np.float32)
+    dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (1, 1), 'SAME')
+    w = rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32)
+    dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), (1, 1, cin, cout), 'same', w_for_decay=dev(w), wd_scale=1e-4)
+    close(dw, dw_ref + 1e-4 * w)
+    close(db, db_ref)
+    dw2, db2 = ops.conv2d_bwd_filter(dev(x), dev(dpre), (1, 1, cin, cout), 'same', w_for_decay=dev(w), wd_scale=1e-4)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('shape', [(1, 300, 260, 'VALID'), (2, 190, 171, 'SAME'), (1, 263, 250, 'VALID'), (3, 160, 130, 'SAME')],
+                         ids=['1x300x260_valid', '2x190x171_same', '1x263x250_valid', '3x160x130_same'])
+def test_wgrad_5x5_32_to_3_kw_columns_route_vs_oracle(shape, ops):
+    """Filter gradient of SRCNN's reconstruction layer on inputs of more than 60,000 output pixels: wgrad_kwcols_kernel, (kw, co)
+    pairs as the MFMA's columns (10 MFMAs per 4 input columns instead of 50 per 4 pixels).  VALID and SAME, strips narrower than
+    60 columns, tiles shorter than 8 rows, several images: against the oracle, deterministic, and beside the cursor kernel
+    (srx_set_wgrad_path(0))."""
+    from ml_super_resolution_amd import _lib
+    N, H, W, pad = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('kwcols',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, 32)).astype(np.float32)
+    oh, ow = (H, W) if pad == 'SAME' else (H - 4, W - 4)
+    dpre = rng.normal(0, 1, (N, oh, ow, 3)).astype(np.float32)
+    dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (5, 5), pad)
+    xd, dd = dev(x), dev(dpre)
+    dw, db = ops.conv2d_bwd_filter(xd, dd, (5, 5, 32, 3), pad)
+    close(dw, dw_ref)
+    close(db, db_ref)
+    dw2, db2 = ops.conv2d_bwd_filter(xd, dd, (5, 5, 32, 3), pad)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    old = _lib.lib().srx_set_wgrad_path(0)
+    try:
+        dw0, db0 = ops.conv2d_bwd_filter(xd, dd, (5, 5, 32, 3), pad)
+    finally:
+        _lib.lib().srx_set_wgrad_path(old)
+    close(dw0, dw_ref)
+    assert (dw0.double() - dw.double()).abs().max().item() <= 4e-6 * dw.abs().max().item()

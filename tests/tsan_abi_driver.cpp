@@ -23,6 +23,8 @@ bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t
 bool launch_conv_kwrows(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 hipError_t launch_reduce_partials(const float*, int, int, int, int, float*, float*, const float*, float, hipStream_t) { return hipSuccess; }
 hipError_t launch_reduce_partials_pairs(const float*, int, int, int, int, float*, float*, int, int, hipStream_t) { return hipSuccess; }
+bool launch_wgrad_kwcols(const ConvKey&, const WgradArgs&, int, long, int*, hipStream_t, hipError_t* e) { *e = hipSuccess; return false; }
+bool launch_wgrad_1x1(const ConvKey&, const WgradArgs&, int, int*, hipStream_t, hipError_t* e) { *e = hipSuccess; return false; }
 bool launch_wgrad_rows_strip(const ConvKey&, const WgradArgs&, int, size_t, bool, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
 bool launch_wgrad_lin_pairs(const ConvKey&, const WgradPairs&, int, int, bool, size_t, hipStream_t, hipError_t* e) { *e = hipSuccess; return true; }
 hipError_t launch_subpixel(const float*, float*, int, int, int, int, int, bool, const SubpixelTune&, hipStream_t) { return hipSuccess; }
