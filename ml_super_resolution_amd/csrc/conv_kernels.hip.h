@@ -1762,12 +1762,18 @@ __device__ __forceinline__ float dpre_step_now(DpreSeq& q, const DpreGeo& D, __a
 // may be narrower); the x tile is staged with the strip variant of the scalar stager (edge halo columns loaded as
 // zeros), the dpre walk only needs the strip's width as the number of real positions per tile row and the image's
 // row pitch in the row-wrap correction (which then has the other sign: a tile row is shorter than an image row).
-template <int KH, int KW, int CINP, int NCH, int MINW, bool Z>
+// PACK3 (RGB-input layers: SRCNN 9x9 3 -> 64, ESPCN 5x5 3 -> 64; CINP must be 4): the LDS pixel is 3 floats and the MFMA's rows are
+// (kh, kw * 3 + ci) -- 27 per filter row for 9x9: 243 rows in 4 groups of 64 instead of 81 x 4 = 324 in 6 (a quarter of them the
+// zero fourth channel): 16 instead of 24 MFMAs per step.  A lane's four rows are four consecutive (kw, ci) values -- across a
+// filter-row end they are not consecutive floats --, so a fragment is four ds_read_b32 at four per-lane bases.
+template <int KH, int KW, int CINP, int NCH, int MINW, bool Z, bool PACK3 = false>
 __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PS = Lds<CINP>::PS;
+    static_assert(!PACK3 || (CINP == 4 && !Z), "PACK3: 3-channel input staged as 3-float pixels, full-width tiles");
+    constexpr int PS = PACK3 ? 3 : Lds<CINP>::PS;
     constexpr int TAPS = KH * KW;
-    constexpr int ROWS = TAPS * CINP;
+    constexpr int ROWS = PACK3 ? KH * KW * 3 : TAPS * CINP;
+    constexpr int NXB = PACK3 ? 4 : 1;           // per-lane bases of a fragment stream
     constexpr int Q = (ROWS + 63) / 64;
     constexpr int NQP = 4 / NCH;             // waves sharing a cout chunk split the q's
     constexpr int QW = (Q + NQP - 1) / NQP;  // q's (LDS fragments per step) of this wave
@@ -1791,20 +1797,30 @@ __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
     char* ldsb = reinterpret_cast<char*>(lds);
 
     // per-lane LDS byte offset of (position kq of a step, the lane's tap / channels) for each of its q's
-    int xb[QW];
+    int xb[QW][NXB];
 #pragma unroll
     for (int k = 0; k < QW; ++k) {
         const int q = qpart + k * NQP;
-        int R = 64 * q + 4 * li;  // first of the lane's 4 rows (all 4 share the tap since CINP % 4 == 0)
-        if (q >= Q || R >= ROWS) R = 0;
-        const int tap = R / CINP, ci = R % CINP;
-        xb[k] = ((kq + (tap / KW) * a.RS + (tap % KW)) * PS + ci) * 4;
+        if constexpr (PACK3) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int R = 64 * q + 4 * li + g;
+                if (q >= Q || R >= ROWS) R = 0;          // (rows past the filter: any finite operand, never written out)
+                const int kh = R / (3 * KW), rem = R % (3 * KW);
+                xb[k][g] = ((kq + kh * a.RS) * PS + rem) * 4;
+            }
+        } else {
+            int R = 64 * q + 4 * li;  // first of the lane's 4 rows (all 4 share the tap since CINP % 4 == 0)
+            if (q >= Q || R >= ROWS) R = 0;
+            const int tap = R / CINP, ci = R % CINP;
+            xb[k][0] = ((kq + (tap / KW) * a.RS + (tap % KW)) * PS + ci) * 4;
+        }
     }
     // the whole tile buffer starts out as zeros: pad columns (never written by the scalar staging below) and
     // the slots past a short tile that the last step may touch (their dpre operand is 0, they must be finite)
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int n16 = (a.zero_slot + 4) * PS / 4;     // (the host allocates 4 slots past the largest tile)
+        const int n16 = (a.zero_slot + 4) * (PACK3 ? 4 : PS) / 4;     // (the host allocates 4 slots past the largest tile; PACK3: sized for 4-float slots)
         for (int i = tid; i < n16; i += 256) reinterpret_cast<f32x4*>(lds)[i] = z;
     }
     // scalar staging (see conv_pipe_kernel) when the channels fit exactly, else the generic stager
@@ -1884,6 +1900,32 @@ __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + ((size_t)n * a.H * a.W - a.pad_l) * CINP, 0, (a.H * a.W + a.pad_l) * CINP * 4, 0x00020000);
             stage_tile_scalar<CINP, 6, Z, Z>(qi, qc, SG, xrs, voff_lane, wl_lane);
+        } else if constexpr (PACK3) {
+            // 3-float pixels: slot s <-> (row s / RS, column s % RS) of the tile; out-of-image slots are zeros
+            const int n_need = (th + KH - 1) * a.RS + (KW - 1);
+            const float* xn = a.x + (size_t)n * a.H * a.W * 3;
+            for (int s0 = tid; s0 < n_need; s0 += 4 * 256) {
+                float v[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = s0 + j * 256;
+                    const int r = fdiv_small(sl < n_need ? sl : 0, a.inv_rs, a.RS);
+                    const int c = sl - r * a.RS;
+                    const int ih = h - a.pad_t + r, iw = c - a.pad_l;
+                    const bool ok = (sl < n_need) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                    const unsigned off = ok ? (unsigned)((ih * a.W + iw) * 3) : 0u;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { const float t = xn[off + e]; v[j][e] = ok ? t : 0.f; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = s0 + j * 256;
+                    if (sl < n_need) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) lds[sl * 3 + e] = v[j][e];
+                    }
+                }
+            }
         } else {
             stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, -a.pad_l, a.RS, a.inv_rs,
                              (th + KH - 1) * a.RS + (KW - 1), tid);
@@ -1905,10 +1947,21 @@ __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
         for (int j = 0; j < PF; ++j) bq[j] = dpre_step_now(dq, DG, brs, voff_b, voff_bn);
         bq[3] = 0.f;
 
-        int xw[QW];      // window base of each fragment stream
+        int xw[QW][NXB];      // window base of each fragment stream
 #pragma unroll
-        for (int k = 0; k < QW; ++k) xw[k] = xb[k];
-        auto read_x = [&](int k, int uu) -> f32x4 { return *reinterpret_cast<const f32x4*>(ldsb + xw[k] + uu * XSTEP); };
+        for (int k = 0; k < QW; ++k)
+#pragma unroll
+            for (int g = 0; g < NXB; ++g) xw[k][g] = xb[k][g];
+        auto read_x = [&](int k, int uu) -> f32x4 {
+            if constexpr (PACK3) {
+                f32x4 v;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const float*>(ldsb + xw[k][g] + uu * XSTEP);
+                return v;
+            } else {
+                return *reinterpret_cast<const f32x4*>(ldsb + xw[k][0] + uu * XSTEP);
+            }
+        };
         f32x4 ring[RN];
 #pragma unroll
         for (int f = 0; f < LA; ++f) ring[f] = read_x(f % QW, f / QW);
@@ -1942,7 +1995,9 @@ __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < QW; ++k) xw[k] += U * XSTEP;
+            for (int k = 0; k < QW; ++k)
+#pragma unroll
+                for (int g = 0; g < NXB; ++g) xw[k][g] += U * XSTEP;
         }
         u += th;
     }
@@ -1960,7 +2015,8 @@ __device__ __forceinline__ void wgrad_lin_body(const WgradArgs& a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int R = 64 * q + 4 * (4 * kq + r) + g;
-                const int tap = R / CINP, ci = R % CINP;
+                // (PACK3: row R = (kh, kw * 3 + ci) -> the same HWIO index: ((kh KW + kw) 3 + ci) = R)
+                const int tap = PACK3 ? R / 3 : R / CINP, ci = PACK3 ? R % 3 : R % CINP;
                 if (R < ROWS && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
             }
         }
@@ -1977,6 +2033,11 @@ __global__ __launch_bounds__(256, MINW) void wgrad_lin_kernel(const WgradArgs a)
 template <int KH, int KW, int CINP, int NCH, int MINW>
 __global__ __launch_bounds__(256, MINW) void wgrad_lin_strip_kernel(const WgradArgs a) {
     wgrad_lin_body<KH, KW, CINP, NCH, MINW, true>(a);
+}
+// RGB-input layers (Cin = 3) with the packed row space, see wgrad_lin_body
+template <int KH, int KW, int NCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_lin_pack3_kernel(const WgradArgs a) {
+    wgrad_lin_body<KH, KW, 4, NCH, MINW, false, true>(a);
 }
 // The filter gradients of a layer wider than 64 channels on channel-blocked tensors: every (input block, output block)
 // pair is an independent 64 -> 64 problem of the same geometry; blockIdx.y picks the pair, the body never looks at it.

@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_nt, kwrows_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -42,6 +42,7 @@ Knobs read_knobs() {
     k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 60000);   // 5x5 32->3 on conv_kwrows_kernel from this many output pixels (negative: never)
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
+    k.wgrad_pack3 = env_int("SRX_WGRAD_PACK3", 1);             // 0: RGB-input 9x9 / 5x5 filter gradients on the cursor kernel's 4-channel rows (A/B)
     k.wgrad_nt = env_int("SRX_WGRAD_NT", 1);                   // strip filter gradient: dpre loads marked non-temporal (A/B)
     k.subpixel_chunk_kb = env_int("SRX_SUBPIXEL_CHUNK_KB", 24);   // sub-pixel map: chunk size bound, double buffering,
     k.subpixel_db = env_int("SRX_SUBPIXEL_DB", 1);                // persistent-grid cap (tuning experiments)
@@ -632,6 +633,7 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
         wdone = launch_wgrad_rows_strip(k, a, wgrid, 2 * lin_lds, knobs().wgrad_nt != 0, s, &err);
         if (!wdone) wgrid = p.grid;
     }
+    if (!wdone && knobs().wgrad_pack3 && lin_ok && lin_lds <= 80 * 1024 && d->Cin == 3) wdone = launch_wgrad_lin_pack3(k, a, p.grid, lin_lds, s, &err);
     if (wdone) {
     } else if (lin_strip_ok && launch_wgrad_lin_strip(k, a, p.grid, lin_lds, s, &err)) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
