@@ -356,8 +356,8 @@ bool launch_conv_kwrows(const ConvKey& k, const ConvArgs& a, long min_pixels, hi
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else (void)hipGetLastError();
     }
-    const long tiles = (units + TH - 1) / TH;
-    const int grid = (int)(tiles < cus ? tiles : cus);
+    const long ranges = (units + 1) / 2;                   // (mid-size inputs: every CU gets rows, a tile is then shorter than TH)
+    const int grid = (int)(ranges < cus ? ranges : cus);
     const size_t lds = ((size_t)(TH + 4) * 64 * Lds<32>::PS + kWaves * 64 * 20) * sizeof(float);
     // (> 64 KiB of dynamic LDS needs the attribute: raised once per host thread, outside any stream capture of later launches)
     static thread_local bool configured = false;

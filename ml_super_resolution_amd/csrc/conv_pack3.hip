@@ -1,0 +1,144 @@
+// conv_pack3.hip -- forward convolution of the RGB-INPUT layers on large inputs: SRCNN's patch extraction 9x9 3 -> 64
+// (srcnn/srcnn.py:100-109) and ESPCN's f1 5x5 3 -> 64 (espcn/espcn/model_espcn.py:30-38).  conv_mfma_kernel stages such an
+// input as 4-float pixels (3 channels + a zero) and spends one MFMA per tap: its K = 4 slots hold 3 useful products, 81 / 25
+// MFMAs per 16 pixels and 16 output channels.  Here the LDS pixel is 3 floats, so the 3 KW values (kw, ci) of one filter row are
+// CONSECUTIVE floats and K simply runs along them, 4 at a time: ceil(3 KW / 4) MFMAs per filter row -- 63 instead of 81 for 9x9,
+// 20 instead of 25 for 5x5 -- with the B fragment of MFMA j a plain `ds_read_b32` at (pixel, 4 j + lane's k) and the last
+// MFMA's unused slots weighted zero.  Exact fp32; the products of an output are the same, grouped into MFMAs differently, so
+// the results agree with conv_mfma_kernel to rounding, not bit for bit: the route starts at 60,000 output pixels, beyond the
+// windows of the one-launch ESPCN / SRCNN kernels (whose tests demand bit-equality with the per-layer launches).
+//
+// One workgroup of 8 waves per CU; a tile is 32 output rows x 64 output columns (its input halo: <= 40 x 72 pixels = 34.6 KB);
+// wave = (16-channel chunk, row parity): it walks its rows, four 16-pixel sub-tiles (= the strip's 64 columns) at a time,
+// MFMAs pinned in blocks of 4 (one per sub-tile, one weight register) with the LDS reads of the next block issued first;
+// the bias is the accumulators' initial value, the activation and the 16-byte stores follow each row.
+#include "launchers.h"
+namespace srx {
+namespace {
+
+constexpr int kTH = 32, kTW = 64, kNW = 8;
+
+__device__ __forceinline__ void mfma4_shared_a(f32x4 (&c)[4], float w, float b0, float b1, float b2, float b3) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %4, %6, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n\t" "v_mfma_f32_16x16x4_f32 %3, %4, %8, %3"
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "v"(w), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs a, int units_total) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KR = 3 * KW;                  // (kw, ci) values of one filter row
+    constexpr int NJ = (KR + 3) / 4;            // MFMAs per filter row
+    constexpr int NBLK = KH * NJ;
+    constexpr int RSW = kTW + KW - 1;           // input columns of a tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave & 3, par = wave >> 2;
+    const int co = 16 * chunk + li;             // A operand: the lane's output channel
+
+    // stationary weights: wr[kh][j] = w[kh][k / 3][k % 3][co], k = 4 j + kq (zero past the filter row)
+    float wr[NBLK];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int kk = 4 * j + kq;
+            const bool ok = kk < KR && co < a.Cout;
+            const float v = a.w[ok ? ((size_t)(kh * KW) * 3 + kk) * a.Cout + co : 0];      // ((kh KW + kw) 3 + ci) = kh KW 3 + k
+            wr[kh * NJ + j] = ok ? v : 0.0f;
+        }
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    const int cb = 16 * chunk + 4 * kq;         // D layout: the lane's four output channels
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cb + e < a.Cout) bias4[e] = a.bias[cb + e];
+    }
+    const float slope = act_slope(a.act);
+
+    const int u0 = (int)(((long)blockIdx.x * units_total) / gridDim.x), u1 = (int)(((long)(blockIdx.x + 1) * units_total) / gridDim.x);
+    for (int u = u0; u < u1;) {
+        // units are the output rows of the column strips (a contiguous range per workgroup); a tile = up to kTH of them
+        const int h0 = u % a.OH;
+        const int t2 = u / a.OH;
+        const int tx = t2 % a.NTX, n = t2 / a.NTX;
+        const int ow0 = tx * kTW;
+        int th = a.OH - h0 < kTH ? a.OH - h0 : kTH;
+        if (u1 - u < th) th = u1 - u;
+        const int tw = a.OW - ow0 < kTW ? a.OW - ow0 : kTW;
+        lds_barrier();
+        {
+            // the input halo as 3-float pixels: float f of tile row r <-> image float (ow0 - pad_l) 3 + f of row h0 - pad_t + r
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)n * a.H * a.W * 3, 0, a.H * a.W * 3 * 4, 0x00020000);
+            const int rows = th + KH - 1, rowf = RSW * 3;
+            const int c0 = (ow0 - a.pad_l) * 3;
+            for (int i = tid; i < rows * rowf; i += 64 * kNW) {
+                const int r = i / rowf, f = i - r * rowf;
+                const int ih = h0 - a.pad_t + r, cf = c0 + f;
+                const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)cf < (unsigned)(a.W * 3));
+                lds[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (ih * a.W * 3 + cf) * 4 : kOobOffset, 0, 0));
+            }
+        }
+        lds_barrier();
+        float* yn = a.y + ((size_t)n * a.OH + h0) * a.OW * a.Cout;
+        for (int r = par; r < th; r += 2) {
+            // B operand of sub-tile g (columns 16 g + li), block (kh, j): float ((r + kh) RSW + 16 g + li) 3 + 4 j + kq
+            const float* px = lds + (r * RSW + li) * 3 + kq;
+            f32x4 acc[4] = {bias4, bias4, bias4, bias4};
+            float c0 = px[0], c1 = px[48], c2 = px[96], c3 = px[144];
+#pragma unroll
+            for (int t = 0; t < NBLK; ++t) {
+                float n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+                if (t + 1 < NBLK) {
+                    const int kh1 = (t + 1) / NJ, j1 = (t + 1) % NJ;
+                    const float* q = px + kh1 * RSW * 3 + 4 * j1;
+                    n0 = q[0]; n1 = q[48]; n2 = q[96]; n3 = q[144];
+                }
+                mfma4_shared_a(acc, wr[t], c0, c1, c2, c3);
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            }
+            // MFMA results are read by VALU code next: software covers the result latency (the MFMAs above are asm)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            if (cb < a.Cout) {
+                float* yo = yn + ((size_t)r * a.OW + ow0 + li) * a.Cout + cb;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (16 * g + li < tw) *reinterpret_cast<f32x4*>(yo + (size_t)16 * g * a.Cout) = act_apply4(acc[g], a.act, slope);
+            }
+        }
+        u += th;
+    }
+}
+
+}  // namespace
+
+// Returns true when this route took the launch.  min_pixels: below it the layer stays on conv_mfma_kernel.
+bool launch_conv_pack3(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err) {
+    if (k.wt || a.skip || a.mask || a.d2s_r || a.stride != 1 || a.post_relu) return false;
+    if (a.Cin != 3 || a.Cout != 64 || !((k.kh == 9 && k.kw == 9) || (k.kh == 5 && k.kw == 5))) return false;
+    if ((long)a.N * a.OH * a.OW < min_pixels) return false;
+    if ((long)a.H * a.W * 3 * 4 >= (1L << 31) - 4096) return false;
+    ConvArgs b = a;
+    b.NTX = (a.OW + kTW - 1) / kTW;
+    const long units = (long)a.N * b.NTX * a.OH;
+    if (units >= (1L << 31)) return false;
+    int cus = 256;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else (void)hipGetLastError();
+    }
+    // every CU gets a range of strip rows (at least two: the two row parities of the waves); a tile is up to kTH of them
+    const long ranges = (units + 1) / 2;
+    const int grid = (int)(ranges < cus ? ranges : cus);
+    const size_t lds = (size_t)(kTH + k.kh - 1) * (kTW + k.kw - 1) * 3 * sizeof(float) + 16;     // (+ the zero-weighted slots past the last pixel)
+    if (k.kh == 9) hipLaunchKernelGGL((conv_pack3_kernel<9, 9>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
+    else hipLaunchKernelGGL((conv_pack3_kernel<5, 5>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
+    *err = hipGetLastError();
+    return true;
+}
+}  // namespace srx

@@ -321,7 +321,8 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // SRCNN's 5x5 32 -> 3 reconstruction layer on large inputs: (kw, co) pairs as the MFMA's rows -- see conv_kwrows.hip.
     // Results agree with the kernels below to rounding (another summation order), so the route starts beyond the window
     // of the one-launch SRCNN kernel, whose tests demand bit-equality with these per-layer launches.
-    if (knobs().kwrows_min_pixels >= 0 && launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err)) {
+    if (knobs().kwrows_min_pixels >= 0 && (launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err) ||
+                                           launch_conv_pack3(k, a, knobs().kwrows_min_pixels, s, &err))) {     // (RGB-input 9x9 / 5x5: conv_pack3.hip)
         if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
         return SRX_OK;
     }

@@ -624,3 +624,28 @@ def test_wgrad_5x5_32_to_3_kw_columns_route_vs_oracle(shape, ops):
         _lib.lib().srx_set_wgrad_path(old)
     close(dw0, dw_ref)
     assert (dw0.double() - dw.double()).abs().max().item() <= 4e-6 * dw.abs().max().item()
+
+
+@pytest.mark.parametrize('shape', [(1, 300, 260, 9, 'VALID', 'relu'), (2, 190, 171, 5, 'SAME', 'tanh'), (1, 263, 250, 9, 'SAME', None), (3, 170, 131, 5, 'VALID', 'relu')],
+                         ids=['1x300x260_k9_valid', '2x190x171_k5_same', '1x263x250_k9_same', '3x170x131_k5_valid'])
+def test_conv_rgb_input_packed_k_route_vs_oracle(shape, ops):
+    """The RGB-input layers (SRCNN 9x9 3 -> 64, srcnn/srcnn.py:100-109; ESPCN 5x5 3 -> 64, espcn/espcn/model_espcn.py:30-38) on
+    inputs of more than 60,000 output pixels: conv_pack3_kernel, 3-float LDS pixels with (kw, ci) running along the MFMA's K
+    (63 / 20 MFMAs per 16 pixels instead of 81 / 25).  VALID and SAME (zero padding inside the tile), strips narrower than 64
+    columns, tiles shorter than 32 rows; against the oracle, deterministic, and beside the 4-float-pixel MFMA kernel on a cut
+    of the input below the threshold (same products, other grouping: agreement to rounding)."""
+    N, H, W, k, pad, act = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('pack3',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(k * k * 3), (k, k, 3, 64)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (64,)).astype(np.float32)
+    ref = O.c_conv2d_fwd(x, w, b, pad, act)
+    assert ref.shape[0] * ref.shape[1] * ref.shape[2] > 60000
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    close(y, ref)
+    assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, pad, act))
+    y1 = ops.conv2d_fwd(xd[:1, :100].contiguous(), wd, bd, pad, act)          # below the threshold: conv_mfma_kernel
+    close(y1, O.c_conv2d_fwd(x[:1, :100], w, b, pad, act))
+    rows = y1.shape[1] - (0 if pad == 'VALID' else k // 2)
+    assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
