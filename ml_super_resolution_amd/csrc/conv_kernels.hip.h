@@ -1691,6 +1691,112 @@ __global__ __launch_bounds__(256, MINW) void wgrad_mfma_kernel(const WgradArgs a
 
 
 // ---------------------------------------------------------------------------------------------
+// Generic filter gradient for filter shapes outside the tuned set (runtime KH, KW -- the counterpart of
+// conv_mfma_generic_kernel, so that the C ABI accepts the same layers in all three directions).  The cursor kernel above with
+// the (tap, ci) rows cut into passes of at most 9 taps (the accumulators of 9 x CINP rows are what fits the register file):
+// pass `tap0` accumulates the rows of taps tap0 .. tap0 + ntaps - 1 over all pixels and writes them into the workgroup's
+// partial; the host launches ceil(KH KW / 9) passes with the same grid, then the usual reduction.  Same numerics; slower (the
+// inputs are read once per pass).  Stride 1.
+// ---------------------------------------------------------------------------------------------
+template <int CINP, int NCH>
+__global__ __launch_bounds__(256, 2) void wgrad_generic_kernel(const WgradArgs a, int KH, int KW, int tap0, int ntaps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PS = Lds<CINP>::PS;
+    constexpr int TPASS = 9;
+    constexpr int ROWS = TPASS * CINP;
+    constexpr int Q = (ROWS + 63) / 64;
+    constexpr int NQP = 4 / NCH;
+    constexpr int QW = (Q + NQP - 1) / NQP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int chunk = wave % NCH, qpart = wave / NCH;
+    const int cout0 = chunk * 16;
+    const int co = cout0 + li;
+    const bool co_ok = co < a.Cout;
+    const int co_c = co_ok ? co : a.Cout - 1;
+    int toff[QW];
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        int R = 64 * q + 4 * li;
+        int tap = tap0 + R / CINP;
+        if (q >= Q || R >= ROWS || tap >= KH * KW) { R = 0; tap = tap0; }      // (rows of no tap: any finite operand, never written out)
+        toff[k] = ((tap / KW) * a.RS + (tap % KW)) * PS + R % CINP;
+    }
+    const int zaddr = a.zero_slot * PS + (4 * li) % CINP;
+    if (tid < PS) lds[a.zero_slot * PS + tid] = 0.f;
+    f32x4 acc[QW][4];
+#pragma unroll
+    for (int k = 0; k < QW; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[k][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const long G_ = gridDim.x;
+    const int u0 = (int)(((long)blockIdx.x * a.units_total) / G_);
+    const int u1 = (int)(((long)(blockIdx.x + 1) * a.units_total) / G_);
+    int u = u0;
+    while (u < u1) {
+        const int h = u % a.OH;
+        const int t = u / a.OH;
+        const int tx = t % a.NTX;
+        const int n = t / a.NTX;
+        int th = a.TH;
+        if (a.OH - h < th) th = a.OH - h;
+        if (u1 - u < th) th = u1 - u;
+        const int ow0 = tx * a.TW;
+        const int tw = (a.OW - ow0 < a.TW) ? (a.OW - ow0) : a.TW;
+        const int n_need = (th - 1 + KH) * a.RS + (KW - 1);
+        lds_barrier();
+        stage_tile<CINP>(lds, a.x, n, a.H, a.W, a.Cin, h - a.pad_t, ow0 - a.pad_l, a.RS, a.inv_rs, n_need, tid);
+        lds_barrier();
+        const int npx = th * tw;
+        const int nsteps = (npx + 3) >> 2;
+        const float* dbase = a.dpre + (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout + co_c;
+        // per-lane cursor: lane group kq takes pixel 4 step + kq of the tile
+        int p = kq, c = 0, xaddr = 0, boff = 0;
+        {
+            const int r0 = fdiv_small(kq < npx ? kq : 0, 1.0f / (float)tw, tw);
+            c = (kq < npx ? kq : 0) - r0 * tw;
+            xaddr = (r0 * a.RS + c) * PS; boff = (r0 * a.OW + c) * a.Cout;
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            const bool live = p < npx;
+            const float b = live ? dbase[boff] : 0.f;
+            bsum += co_ok ? b : 0.f;
+#pragma unroll
+            for (int k = 0; k < QW; ++k) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(lds + (live ? xaddr + toff[k] : zaddr));
+                mfma4_wgrad(acc[k], xv, b);
+            }
+            p += 4; c += 4; xaddr += 4 * PS; boff += 4 * a.Cout;
+            while (c >= tw) { c -= tw; xaddr += (a.RS - tw) * PS; boff += (a.OW - tw) * a.Cout; }
+        }
+        u += th;
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    float* pw = a.part + (size_t)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = qpart + k * NQP;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 64 * q + 4 * (4 * kq + r) + g;
+                const int lt = R / CINP, ci = R % CINP, tap = tap0 + lt;
+                if (R < ROWS && lt < ntaps && tap < KH * KW && ci < a.Cin && co_ok) pw[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[k][g][r];
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (tap0 == 0 && qpart == 0 && kq == 0 && co_ok) pw[(size_t)KH * KW * a.Cin * a.Cout + co] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad, linear walk (full-width tiles).  Same data flow as wgrad_mfma_kernel -- accumulators
 // stationary, x from the LDS halo tile, dpre from global -- but the K loop walks the PADDED positions
 // p' = orow*RS + ocol of the tile, 4 per step, instead of the real pixels.  In that space the x operand

@@ -638,9 +638,9 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
     if (wdone) {
     } else if (lin_strip_ok && launch_wgrad_lin_strip(k, a, p.grid, lin_lds, s, &err)) {
     } else if (lin_ok && lin_lds <= 80 * 1024 && launch_wgrad_lin(k, a, p.grid, lin_lds, s, &err)) {
-    } else if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err))
-        return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d", d->KH, d->KW, p.cinp,
-                    p.nch);
+    } else if (!launch_wgrad(k, a, p.grid, wg_lds, s, &err) && !(wg_lds <= 80 * 1024 && launch_wgrad_generic(k, a, p.grid, wg_lds, s, &err)))
+        return fail(SRX_ERR_UNSUPPORTED, "no wgrad instance for %dx%d, Cin<=%d, Cout chunks %d%s", d->KH, d->KW, p.cinp,
+                    p.nch, s2 ? " at stride 2" : "");
     if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "wgrad launch failed: %s", hipGetErrorString(err));
     *n_partials = wgrid;
     return SRX_OK;

@@ -75,6 +75,28 @@ hipError_t launch_reduce_partials(const float* part, int G, int stride, int wn, 
     return hipGetLastError();
 }
 
+// Shapes outside the tuned set: passes of 9 taps over runtime KH x KW (wgrad_generic_kernel)
+bool launch_wgrad_generic(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
+    if (a.stride != 1) return false;
+    const int taps = k.kh * k.kw;
+    *err = hipSuccess;
+    for (int tap0 = 0; tap0 < taps && *err == hipSuccess; tap0 += 9) {
+        const int nt = taps - tap0 < 9 ? taps - tap0 : 9;
+#define SRX_WGRAD_GENERIC(CI, NC)                                                                                        \
+        if (k.cinp == CI && k.nch == NC) {                                                                               \
+            hipLaunchKernelGGL((wgrad_generic_kernel<CI, NC>), dim3(grid), dim3(256), lds, s, a, k.kh, k.kw, tap0, nt); \
+            *err = hipGetLastError();                                                                                    \
+            continue;                                                                                                    \
+        }
+        SRX_WGRAD_GENERIC(64, 4) SRX_WGRAD_GENERIC(64, 2) SRX_WGRAD_GENERIC(64, 1)
+        SRX_WGRAD_GENERIC(32, 4) SRX_WGRAD_GENERIC(32, 2) SRX_WGRAD_GENERIC(32, 1)
+        SRX_WGRAD_GENERIC(4, 4) SRX_WGRAD_GENERIC(4, 2) SRX_WGRAD_GENERIC(4, 1)
+#undef SRX_WGRAD_GENERIC
+        return false;
+    }
+    return true;
+}
+
 bool launch_wgrad(const ConvKey& k, const WgradArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err) {
     SRX_WGRAD_CASE(3, 3, 64, 4, 2)
     SRX_WGRAD_CASE(3, 3, 64, 2, 2)

@@ -65,7 +65,7 @@ def run(cases, seed, verbose=True):
                 dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), wt.shape, pad)
                 checks += [('dw', dw.cpu().numpy(), dw_ref), ('db', db.cpu().numpy(), db_ref)]
             except Exception as exc:
-                # forward / dgrad have a generic kernel for shapes outside the tuned set; the filter gradient does not:
+                # (until round 4 the filter gradient had no generic kernel and refused such shapes; kept for stride-2 odd shapes)
                 # such shapes (none of them a layer of the reference) must come back as SRX_ERR_UNSUPPORTED, not as UB
                 if 'no wgrad instance' not in str(exc):
                     raise

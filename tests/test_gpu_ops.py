@@ -649,3 +649,24 @@ def test_conv_rgb_input_packed_k_route_vs_oracle(shape, ops):
     close(y1, O.c_conv2d_fwd(x[:1, :100], w, b, pad, act))
     rows = y1.shape[1] - (0 if pad == 'VALID' else k // 2)
     assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 11, 13, 7, 7, 8, 5, 'SAME'), (1, 9, 9, 4, 4, 3, 16, 'SAME'), (2, 10, 12, 2, 2, 64, 64, 'VALID'), (1, 20, 20, 7, 7, 32, 48, 'VALID'),
+                                   (1, 12, 15, 3, 5, 20, 64, 'SAME'), (3, 8, 70, 5, 5, 64, 33, 'SAME'), (1, 6, 6, 6, 6, 4, 4, 'VALID'), (2, 9, 9, 1, 1, 7, 9, 'SAME')],
+                         ids=lambda s: '%dx%dx%d_k%dx%d_%d-%d_%s' % s)
+def test_generic_filter_gradient_shapes_outside_the_tuned_set(shape, ops):
+    """Filter shapes no tuned wgrad instance covers (7x7, 4x4, 2x2, 3x5, 6x6, ragged channel counts) run wgrad_generic_kernel:
+    the cursor kernel with runtime KH x KW, the (tap, ci) rows cut into passes of 9 taps.  With it the C ABI accepts the same
+    layers in all three directions (forward / data gradient had conv_mfma_generic_kernel since round 1).  Against the oracle,
+    deterministic."""
+    N, H, W, kh, kw, cin, cout, pad = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('gen',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
+    oh, ow = (H, W) if pad == 'SAME' else (H - kh + 1, W - kw + 1)
+    dpre = rng.normal(0, 1, (N, oh, ow, cout)).astype(np.float32)
+    dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (kh, kw), pad)
+    dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), (kh, kw, cin, cout), pad)
+    close(dw, dw_ref)
+    close(db, db_ref)
+    dw2, db2 = ops.conv2d_bwd_filter(dev(x), dev(dpre), (kh, kw, cin, cout), pad)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)

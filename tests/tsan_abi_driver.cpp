@@ -17,7 +17,7 @@ STUB_CONV(launch_conv_k3c64) STUB_CONV(launch_conv_k3c32) STUB_CONV(launch_conv_
 STUB_CONV(launch_pipe_k3c64) STUB_CONV(launch_pipe_other) STUB_CONV(launch_pipe_strip) STUB_CONV(launch_conv_generic)
 #define STUB_WGRAD(name) \
     bool name(const ConvKey&, const WgradArgs&, int, size_t, hipStream_t, hipError_t* err) { *err = hipSuccess; return true; }
-STUB_WGRAD(launch_wgrad) STUB_WGRAD(launch_wgrad_lin) STUB_WGRAD(launch_wgrad_lin_strip) STUB_WGRAD(launch_wgrad_lin_pack3) STUB_WGRAD(launch_wgrad_pipe) STUB_WGRAD(launch_wgrad_rows_full)
+STUB_WGRAD(launch_wgrad) STUB_WGRAD(launch_wgrad_lin) STUB_WGRAD(launch_wgrad_lin_strip) STUB_WGRAD(launch_wgrad_lin_pack3) STUB_WGRAD(launch_wgrad_generic) STUB_WGRAD(launch_wgrad_pipe) STUB_WGRAD(launch_wgrad_rows_full)
 bool launch_wgrad_narrow(const ConvKey&, const WgradArgs&, int, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_pack3(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
