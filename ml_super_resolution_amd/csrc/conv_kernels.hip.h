@@ -78,10 +78,29 @@ struct Lds {
     static constexpr int PS = (CINP == 4) ? 4 : CINP + 4;  // pixel stride in floats
 };
 
+// tanh, branch-free on the hardware's v_exp_f32 / v_rcp_f32 (round 4).  libdevice's tanhf is ~28 VALU instructions in two
+// EXEC-masked branches; every VALU instruction of an epilogue adds to the MFMA time (section 3.0 of DESIGN.md), and ESPCN's two
+// tanh layers spent 69 of 651 us at 720 x 1280 in it.  |x| < 0.55: x + x^3 P(x^2), P a degree-4 minimax fit of (tanh x - x) / x^3
+// (relative error 1e-9 before rounding); otherwise 1 - 2 / (2^(2 |x| log2 e) + 1).  Measured against float64 tanh over 2.2 M
+// points of [-12, 12] and a log sweep down to 1e-8: max relative error 1.9e-7, max absolute error 1e-7; exact limits (+-1 for
+// large |x|, +-0 at +-0, NaN through).  Every fused multiply-add is spelled out, so that all kernels round identically.
+__device__ __forceinline__ float srx_tanhf(float x) {
+    const float ax = fabsf(x);
+    const float x2 = ax * ax;
+    float p = fmaf(x2, -0.006274174898862839f, 0.021071631461381912f);
+    p = fmaf(x2, p, -0.053852297365665436f);
+    p = fmaf(x2, p, 0.13332585990428925f);
+    p = fmaf(x2, p, -0.33333316445350647f);
+    const float small = fmaf(x2 * ax, p, ax);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    return copysignf(ax < 0.55f ? small : big, x);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.0f);
-        case ACT_TANH: return tanhf(v);
+        case ACT_TANH: return srx_tanhf(v);
         case ACT_LRELU: return v > 0.0f ? v : 0.2f * v;
         case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         default: return v;
@@ -217,9 +236,13 @@ __device__ __forceinline__ float act_slope(int act) {
 // tanh / sigmoid live OUT OF LINE: inlined, their code (x4 elements x every accumulator x every
 // group body) pushed the 3x3x64 kernel to 60 KB, the size of the instruction cache two CUs share,
 // and the VALU-dense staging / epilogue code then ran at instruction-fetch speed.
-__device__ __attribute__((noinline)) f32x4 act_transcendental4(f32x4 v, int act) {
+// (Round 4: inlined again.  With the 18-instruction branch-free srx_tanhf the code is a few KB per kernel, and the call was the
+// expensive part: `act` arrived in a VGPR, so both activations ran under EXEC masks, and the caller shuffled its live
+// registers around every call -- swapping libdevice's tanhf for srx_tanhf inside the out-of-line function changed nothing
+// (ESPCN f1 at 720 x 1280: 133 -> 135 us); inlining it did.)
+__device__ __forceinline__ f32x4 act_transcendental4(f32x4 v, int act) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
+    for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? srx_tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
     return v;
 }
 

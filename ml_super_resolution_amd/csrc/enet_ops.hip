@@ -334,7 +334,7 @@ __device__ __forceinline__ float gemm_act(float v, int act) {
     if (act == ACT_LRELU) return v > 0.f ? v : 0.2f * v;
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
-    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_TANH) return srx_tanhf(v);
     return v;
 }
 

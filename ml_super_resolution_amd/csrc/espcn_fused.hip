@@ -40,7 +40,7 @@ constexpr int kT2 = (kT + 2) * (kT + 2) * kP2;
 
 __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = srx_tanhf(v[e]);
     return v;
 }
 
