@@ -361,6 +361,12 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
             return SRX_OK;
         }
     }
+    // 3x3 layers of 17..32 output channels that the pipelined family did not take, on large inputs (ESPCN's f2 / f3 on whole
+    // images): one workgroup of 8 waves per CU, see conv_rows3x3.hip.  Bit-identical to the kernels below.
+    if (g_use_pipe && knobs().kwrows_min_pixels >= 0 && launch_conv_rows3x3(k, a, knobs().kwrows_min_pixels, s, &err)) {
+        if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+        return SRX_OK;
+    }
     // Dynamic tile scheduling (one atomic counter) for the two-workgroup kernels, OFF by default: measured
     // 2-5 % slower than the static row split on MI355X (the atomic's round trip is exposed once per tile,
     // and the "tail" of the static split is not wasted: the workgroup left alone runs unstarved).

@@ -670,3 +670,30 @@ def test_generic_filter_gradient_shapes_outside_the_tuned_set(shape, ops):
     close(db, db_ref)
     dw2, db2 = ops.conv2d_bwd_filter(dev(x), dev(dpre), (kh, kw, cin, cout), pad)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('shape', [(1, 420, 400, 32, 32, 'tanh', 0), (3, 260, 231, 32, 27, None, 3), (1, 463, 350, 32, 20, 'relu', 2), (5, 170, 191, 32, 27, None, 0),
+                                   (1, 130, 140, 32, 27, None, 3), (4, 230, 240, 32, 32, 'lrelu', 0)],
+                         ids=['1x420x400_32-32_tanh', '3x260x231_32-27_d2s3', '1x463x350_32-20_d2s2', '5x170x191_32-27', '1x130x140_32-27_d2s3_small', '4x230x240_32-32_lrelu'])
+def test_conv_3x3_rows_route_vs_oracle_and_bit_identical_to_mfma_kernel(shape, ops, conv_path):
+    """3x3 layers from 32 input into 17..32 output channels on inputs of more than 150,000 pixels that the pipelined family does not
+    take (ESPCN's f3 32 -> 27 with the sub-pixel store, on whole images): conv_rows3x3_kernel under srx_set_conv_path(1),
+    conv_mfma_kernel under path 0 (and for the one case below the threshold).  Against the oracle; the two paths must agree BIT FOR BIT (same products, same order);
+    ragged channel counts, the sub-pixel store, strips narrower than 48 columns, tiles shorter than 8 rows."""
+    N, H, W, cin, cout, act, r = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('rows3x3',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, cin)).astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(9 * cin), (3, 3, cin, cout)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (cout,)).astype(np.float32)
+    ref = O.c_conv2d_fwd(x, w, b, 'SAME', act)
+    if r:
+        ref = O.depth_to_space(ref, r)
+    y = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', act, subpixel_r=r)
+    close(y, ref)
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0 = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', act, subpixel_r=r)
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(y, y0)
