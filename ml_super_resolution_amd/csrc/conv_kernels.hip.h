@@ -954,7 +954,7 @@ __device__ __forceinline__ void stage_tile_scalar(StageSeq& qi, StageSeq& qc, co
 template <int MAXG, int AUX>
 struct PipePend {      // a finished group waiting for its epilogue
     f32x4 acc[MAXG];
-    f32x4 aux[AUX ? MAXG : 1];
+    f32x4 aux[(AUX == 1 || AUX == 2) ? MAXG : 1];
     __amdgpu_buffer_rsrc_t yrs;   // wave-uniform: the unit's output pixels
     int m_first, gs;
 };
@@ -963,7 +963,7 @@ struct PipeEpi {
     int cout4;         // Cout * 4
     int sh, rowb;      // column strips: log2(sub-tiles per strip row), bytes of one output row
 };
-// AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add
+// AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add, 3 no aux operand + tanh (ESPCN's f2 on whole images)
 template <int AUX>
 __device__ __forceinline__ PipeEpi pipe_epi_setup(const ConvArgs& a) {
     PipeEpi e;
@@ -1005,7 +1005,10 @@ __device__ __forceinline__ int subtile_soffset(int m, bool live, const PipeEpi& 
 template <int MAXG, int AUX, int NPART, bool Z = false>
 __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd, int i, const PipeEpi& ep, int vst) {
     f32x4 v = pd.acc[i];
-    if (AUX == 1) {
+    if (AUX == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float f = v[e]; v[e] = srx_tanhf(f); }
+    } else if (AUX == 1) {
         const f32x4 m = pd.aux[AUX ? i : 0];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1072,7 +1075,9 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     constexpr int PS = Lds<CINP>::PS;
     constexpr int NG = CINP / 16;
     constexpr int NBLK = KH * KW * NG;
-    constexpr int NSTW = Z ? 8 : 6;                       // (a strip tile has 6 (TH + 2) / TH passes per group of 4 sub-tiles)
+    // (a strip tile has 6 (TH + 2) / TH passes per group of 4 sub-tiles of the WORKGROUP; with two waves per chunk a wave's
+    // group is half of that work, so it carries 12 passes -- with 8, a third of every tile was left to the exposed drain)
+    constexpr int NSTW = Z ? (NPART == 1 ? 8 : 12) : 6;
     constexpr int NST = (NBLK / 2 < NSTW) ? NBLK / 2 : NSTW;   // staging passes threaded through this group
     constexpr int E0 = NST;                               // first epilogue block
     constexpr int A0 = NST + MAXG;                        // address block
@@ -1081,8 +1086,9 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
     static_assert(NBLK >= NST + MAXG + 2, "group too short for the dealt-out schedule");
     const unsigned long long ts_m = SRX_STAMP();
     f32x4 acc[G];
-    f32x4 aux[AUX ? G : 1];
-    if (AUX) {
+    constexpr bool HASAUX = (AUX == 1 || AUX == 2);
+    f32x4 aux[HASAUX ? G : 1];
+    if (HASAUX) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             aux[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -1173,7 +1179,7 @@ __device__ __forceinline__ void conv_group_pipe(const char* ldsb, const float (&
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) {
         pd.acc[i] = (i < G) ? acc[i < G ? i : 0] : bias4;
-        if (AUX) pd.aux[i] = (i < G) ? aux[i < G ? i : 0] : bias4;
+        if (HASAUX) pd.aux[i] = (i < G) ? aux[i < G ? i : 0] : bias4;
     }
     pd.yrs = un.yrs; pd.m_first = m_first; pd.gs = gs;
     tt[1] += SRX_STAMP() - ts_m;
@@ -1332,7 +1338,7 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
     PipePend<MAXG, AUX> pd;
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) pd.acc[i] = bias4;
-    if (AUX) {
+    if (AUX == 1 || AUX == 2) {
 #pragma unroll
         for (int i = 0; i < MAXG; ++i) pd.aux[i] = bias4;
     }
@@ -1358,8 +1364,8 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
         // (strips: the unit's bytes run from its first pixel to the last pixel of its last row)
         const int unit_bytes = (Z ? (th - 1) * a.OW + a.TW : npx) * ep.cout4;
         un.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_off, 0, unit_bytes, 0x00020000);
-        un.auxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AUX ? auxp + unit_off : a.x), 0,
-                                                     AUX ? unit_bytes : 0, 0x00020000);
+        un.auxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((AUX == 1 || AUX == 2) ? auxp + unit_off : a.x), 0,
+                                                     (AUX == 1 || AUX == 2) ? unit_bytes : 0, 0x00020000);
 
         const int n_sub = (npx + 15) >> 4;
         const int cnt = (n_sub - part + NPART - 1) / NPART;
@@ -1415,7 +1421,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
 // the same for images too wide for full-width tiles: column strips
 template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
 __global__ __launch_bounds__(256, 1) void conv_pipe_strip_kernel(const ConvArgs a) {
-    static_assert(NCH == 4, "strip tiles: one sub-tile sequence per workgroup (NPART == 1)");
+    static_assert(NCH == 4 || NCH == 2, "strip tiles: 64 or 32 output channels");
     conv_pipe_body<KH, KW, CINP, NCH, WT, AUX, true>(a);
 }
 

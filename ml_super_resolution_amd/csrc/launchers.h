@@ -101,6 +101,15 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
             *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, true, 0>, a, grid, lds, s);  \
         return true;                                                                                      \
     }
+// forward only, 32 output channels (two chunks), no aux operand: none / ReLU, or tanh (ESPCN's f2 on whole images)
+#define SRX_PIPE_STRIP_CASE_FWD2(KH, KW, CINP, NCH)                                                       \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && !k.wt && !a.skip && !a.mask) {      \
+        if (a.act == ACT_TANH)                                                                            \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 3>, a, grid, lds, s); \
+        else                                                                                              \
+            *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 0>, a, grid, lds, s); \
+        return true;                                                                                      \
+    }
 #define SRX_WGRAD_LIN_CASE(KH, KW, CINP, NCH, MINW)                                                       \
     if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH) {                                     \
         *err = launch_with_lds(wgrad_lin_kernel<KH, KW, CINP, NCH, MINW>, a, grid, lds, s);               \

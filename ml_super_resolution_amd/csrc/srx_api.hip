@@ -340,8 +340,11 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
                          (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     // Column-strip variant (images too wide for full-width tiles): strips of 16 or 32 columns no wider than the
     // image, one sub-tile sequence per workgroup (64 output channels); any padding.
-    const bool strip_ok = epi_ok && !a.d2s_r && a.stride == 1 && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
-                          p.RS >= ppp && npart == 1 && (a.Cout & 3) == 0 &&
+    // (32 output channels: forward only, no aux operand, and the one shape with a tanh form of the deferred epilogue -- ESPCN's f2)
+    const bool strip2 = npart == 2 && !wt && !a.skip && !a.mask && !a.post_relu && a.Cout == 32 && p.cinp == 64 &&
+                        (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_TANH);
+    const bool strip_ok = (epi_ok || strip2) && !a.d2s_r && a.stride == 1 && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
+                          p.RS >= ppp && (npart == 1 || strip2) && (a.Cout & 3) == 0 &&
                           a.y != a.skip && a.y != a.mask &&   // (the columns two strips share are computed twice: no in-place epilogue operand)
                           (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     if (g_use_pipe && p.cinp >= 16 && strip_ok) {

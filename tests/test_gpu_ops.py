@@ -697,3 +697,28 @@ def test_conv_3x3_rows_route_vs_oracle_and_bit_identical_to_mfma_kernel(shape, o
     finally:
         _lib.lib().srx_set_conv_path(old)
     assert torch.equal(y, y0)
+
+
+@pytest.mark.parametrize('shape', [(1, 300, 260, 'tanh'), (2, 64, 100, 'relu'), (1, 9, 61, None), (3, 33, 64, 'tanh'), (1, 100, 203, 'tanh'), (5, 4, 77, 'relu')],
+                         ids=['1x300x260_tanh', '2x64x100_relu', '1x9x61_none', '3x33x64_tanh', '1x100x203_tanh', '5x4x77_relu'])
+def test_conv_3x3_64_to_32_on_column_strips_of_the_pipelined_kernel(shape, ops):
+    """ESPCN's f2 (3x3 64 -> 32, tanh; espcn/espcn/model_espcn.py:122-126) on images too wide for full-width tiles: since round 4
+    conv_pipe_strip_kernel has a two-chunk instance (two waves per 16-channel chunk share the strip's sub-tiles) with a tanh
+    form of its deferred epilogue.  Against the oracle, and BIT-IDENTICAL to conv_mfma_kernel (srx_set_conv_path(0)): same
+    products, same order, same tanh.  Widths that are / are not multiples of the 32-column strip (the last strip is shifted
+    back), short images, several images per workgroup."""
+    N, H, W, act = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('strip2',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, 64)).astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(9 * 64), (3, 3, 64, 32)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (32,)).astype(np.float32)
+    ref = O.c_conv2d_fwd(x, w, b, 'SAME', act)
+    y = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', act)
+    close(y, ref)
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0 = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', act)
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(y, y0)
