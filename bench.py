@@ -240,7 +240,8 @@ def kernel_source_sha():
 
 
 def measured_traffic():
-    """`roofline.traffic` is NOT measured by this run (PMC counters need rocprofv3 around the process): it is the
+    """Fallback of live_traffic() (rocprofv3 missing, this process itself under a profiler, N > 1, --no-live-traffic):
+    `roofline.traffic` is then NOT measured by this run: it is the
     HBM bytes per launch of the dominant kernel from the committed PMC passes (2*FETCH_SIZE + WRITE_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md), recorded in profiles/traffic.json together with the kernel name and
     the sha of the kernel sources it was measured on.  If the sources have changed since, the value is withheld
@@ -255,6 +256,61 @@ def measured_traffic():
                 % (rec.get('csrc_sha'), sha)}
     return {'traffic': rec['traffic_bytes'], 'traffic_algorithmic': rec.get('algorithmic_bytes'),
             'traffic_source': rec.get('source'), 'traffic_kernel': rec.get('kernel'), 'traffic_csrc_sha': sha}
+
+
+TRAFFIC_KERNEL = 'void srx::conv_pipe_kernel<3, 3, 64, 4, false, 0>(srx::ConvArgs)'
+
+
+def under_profiler():
+    """True when this process itself runs under rocprofv3 (its tool library is preloaded): no second profiler inside."""
+    env = os.environ
+    return any('rocprof' in env.get(k, '').lower() for k in ('LD_PRELOAD', 'HSA_TOOLS_LIB', 'ROCP_TOOL_LIBRARIES')) or \
+        any(k.startswith(('ROCPROF', 'ROCPROFILER_')) for k in env)
+
+
+def live_traffic(timeout_s=240):
+    """`roofline.traffic` measured IN THIS RUN: two child processes `rocprofv3 --kernel-trace --pmc <counter> -- python3
+    scripts/prof_conv.py 10 fwd` (FETCH_SIZE and WRITE_SIZE need a pass each; nothing but --kernel-trace beside --pmc),
+    started BEFORE this process touches the GPU (a process that has initialised the GPU must not start programs).
+    HBM bytes per launch of the dominant kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the counters are in KB and gfx950
+    counts a wide streamed read at half its size (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Returns the roofline keys,
+    or None (then the caller falls back to the committed profiles/traffic.json and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None
+    vals, launches = {}, 0
+    t0 = time.time()
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='srx_pmc_')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            r = subprocess.run([prof, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '--', 'python3',
+                                os.path.join(ROOT, 'scripts', 'prof_conv.py'), '10', 'fwd'], cwd='/tmp', env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row['Counter_Value']) for row in csv.DictReader(open(files[0]))
+                 if row['Kernel_Name'] == TRAFFIC_KERNEL and row['Counter_Name'] == ctr]
+            if not v:
+                return None
+            vals[ctr] = sum(v) / len(v)
+            launches = len(v)
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {'traffic': round((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0),
+            'traffic_algorithmic': 2 * 256 * 41 * 41 * 64 * 4,
+            'traffic_source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over '
+                              'scripts/prof_conv.py 10 fwd, average of %d launches; (2*FETCH_SIZE + WRITE_SIZE) KB' % launches,
+            'traffic_kernel': TRAFFIC_KERNEL, 'traffic_fetch_size_kb': round(vals['FETCH_SIZE'], 1),
+            'traffic_write_size_kb': round(vals['WRITE_SIZE'], 1), 'traffic_seconds': round(time.time() - t0, 1)}
 
 
 def extras(model, dev, stream, x64, y64, px):
@@ -505,10 +561,18 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary north-star numbers')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='do not run the two rocprofv3 --pmc passes; roofline.traffic then comes from profiles/traffic.json')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    # HBM traffic of the dominant kernel, measured by two profiler child processes -- first thing, while this process has
+    # not touched the GPU yet (N = 1 only; not when this process is itself being profiled)
+    traffic = None
+    if args.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_live_traffic and \
+            os.environ.get('SRX_BENCH_LIVE_TRAFFIC', '1') != '0' and not under_profiler():
+        traffic = live_traffic()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -601,7 +665,7 @@ def main():
             'roofline': dict({'bound': 'mfma', 'kernel': 'conv_pipe_kernel<3,3,64,4,fwd> (3x3 64->64 fwd+bias+ReLU)',
                               'achieved': round(achieved_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                              'launch_ms': round(mid_ms, 4)}, **measured_traffic()),
+                              'launch_ms': round(mid_ms, 4)}, **(traffic if traffic is not None else measured_traffic())),
         }
         if allreduce_ms is not None:
             line['allreduce_ms'] = round(allreduce_ms, 4)

@@ -8,7 +8,7 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-scripts/prof_stats.sh r04_bench python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline
+scripts/prof_stats.sh r04_bench python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-live-traffic
 cp gpurun_out/r04_bench.out gpurun_out/r04_bench_line_under_rocprof.json
 scripts/prof_stats.sh r04_recipe python3 scripts/time_vdsr_recipe.py
 cp gpurun_out/r04_recipe.out gpurun_out/r04_recipe_line_under_rocprof.json

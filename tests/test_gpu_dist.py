@@ -225,6 +225,10 @@ def test_bench_default_line_has_the_contract_keys():
     r = line['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert 0.5 < r['frac'] < 1.0 and ('traffic' in r)
+    # HBM bytes of the dominant kernel: measured by bench.py itself (two rocprofv3 --pmc child passes before it touches the
+    # GPU), not replayed from profiles/traffic.json; within a few per cent of the algorithmic bytes (read x once, write y once)
+    assert r['traffic_source'].startswith('measured in this run'), r
+    assert 0.98 < r['traffic'] / r['traffic_algorithmic'] < 1.15, r
     c = line['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert abs(line['value'] - 256 * 1000.0 / line['ms_per_step']) < 0.01 * line['value']
