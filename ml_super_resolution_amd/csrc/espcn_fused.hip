@@ -4,9 +4,9 @@
 // (espcn/espcn/model_espcn.py:117-134 + espcn/espcn/experiment_test.py:171-177).
 //
 // At that size the three layers are 0.57 GFLOP and three launches are three latency-bound ramps (9 + 14 + 9 us of
-// kernel time plus the gaps between dependent launches).  Here a workgroup owns a tile of <= 9x9 LR output pixels and
-// chains the layers through LDS: the input halo (tile grown by 4), t1 on the tile grown by 2 (<= 13x13 x 64 channels),
-// t2 on the tile grown by 1 (<= 11x11 x 32), then the output straight through the sub-pixel map.  The host cuts the
+// kernel time plus the gaps between dependent launches).  Here a workgroup owns a tile of <= 16x16 LR output pixels and
+// chains the layers through LDS: the input halo (tile grown by 4), t1 on the tile grown by 2 (<= 20x20 x 64 channels),
+// t2 on the tile grown by 1 (<= 18x18 x 32), then the output straight through the sub-pixel map.  The host cuts the
 // image into the tile shape that needs the fewest rounds of workgroups and the least MFMA work per tile ([32,17,17]:
 // 2 x 3 tiles of 9 x 6 = 192 workgroups; round 2 used 2 x 2 of 9 x 9 = 128: 29.5 -> 22.7 us).  Positions of t1 / t2 outside the image
 // are stored as zeros (SAME padding pads the LAYER INPUT).  Halo pixels are computed by every tile that needs them
@@ -28,15 +28,19 @@ struct EspcnArgs {
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     float* hr;
     int N, H, W, r, C3;          // C3 = 3 r^2
-    int TY, TX;                  // tile (<= 9 x 9 LR output pixels)
+    int TY, TX;                  // tile (<= 16 x 16 LR output pixels)
     int tiles_y, tiles_x, units;
 };
 
-constexpr int kT = 9;                       // largest tile edge
+constexpr int kT = 16;                      // largest tile edge (round 4: 9 -> 16, see srx_espcn_forward)
 constexpr int kP1 = 68, kP2 = 36;           // LDS pixel strides of t1 (64 + 4) and t2 (32 + 4) in floats
 constexpr int kX0 = (kT + 8) * (kT + 8) * 4;            // input halo, 4 floats per pixel
 constexpr int kT1 = (kT + 4) * (kT + 4) * kP1;
 constexpr int kT2 = (kT + 2) * (kT + 2) * kP2;
+// LDS: t1, then ONE region shared by the input halo and t2 -- the halo is dead once f1 has run (barrier), t2 is dead when the
+// next tile's halo is staged (barrier at the top of the tile loop): 108.8 + 46.7 KB at 16 x 16 tiles (of 160)
+constexpr int kShared = kT2 > kX0 ? kT2 : kX0;
+static_assert((size_t)(kT1 + kShared) * 4 <= 160 * 1024, "tile does not fit the LDS");
 
 __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 #pragma unroll
@@ -78,16 +82,23 @@ __device__ __forceinline__ void espcn_f1_group(const EspcnArgs& a, const float* 
         la[i] = (r * w0 + c) * 4 + kq;
         acc[i] = b1r;
     }
+    // (the LDS reads of tap t + 1 are issued before the MFMAs of tap t: left to itself the compiler reads each value right
+    // before its MFMA and waits out the LDS latency 25 times per group)
+    float b[G], bn[G];
 #pragma unroll
-    for (int kh = 0; kh < 5; ++kh)
+    for (int i = 0; i < G; ++i) b[i] = X0[la[i]];
 #pragma unroll
-        for (int kw = 0; kw < 5; ++kw) {
-            float b[G];
+    for (int t = 0; t < 25; ++t) {
+        if (t + 1 < 25) {
+            const int kh1 = (t + 1) / 5, kw1 = (t + 1) % 5;
 #pragma unroll
-            for (int i = 0; i < G; ++i) b[i] = X0[la[i] + (kh * w0 + kw) * 4];
-#pragma unroll
-            for (int i = 0; i < G; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[kh * 5 + kw], b[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < G; ++i) bn[i] = X0[la[i] + (kh1 * w0 + kw1) * 4];
         }
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[t], b[i], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) b[i] = bn[i];
+    }
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m0 + i * step) + li;
@@ -112,22 +123,37 @@ __device__ __forceinline__ void espcn_f2_group(const EspcnArgs& a, const float* 
         const int tt = t < n2 ? t : 0;
         const int r = tt / w2, c = tt - r * w2;
         la[i] = (r * w1 + c) * kP1 + 4 * kq;
-        acc[i] = b2r;
     }
+    // Fragments of block t + 1 are read before the MFMAs of block t.  Groups of 3 / 4 sub-tiles issue their MFMAs as asm
+    // statements (weights in accumulation registers, the order of LDS reads and MFMAs pinned); the rare groups of 1 / 2
+    // (a tile of <= 2 sub-tiles per wave) go through the builtin.
+    f32x4 b[G], bn[G];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int i = 0; i < G; ++i) b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 b[G];
+    for (int t = 0; t < 36; ++t) {
+        if (t + 1 < 36) {
+            const int tap1 = (t + 1) / 4, g1 = (t + 1) % 4;
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + ((tap / 3) * w1 + (tap % 3)) * kP1 + 16 * g);
+                bn[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + ((tap1 / 3) * w1 + (tap1 % 3)) * kP1 + 16 * g1);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (G >= 3) {
+                if (t == 0 && e == 0) mfma_sub_a_first(acc, b2r, w2r[0], b[0][0], b[1][0], b[2][0], b[G - 1][0]);
+                else mfma_sub_a(acc, w2r[4 * t + e], b[0][e], b[1][e], b[2][e], b[G - 1][e]);
+            } else {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[tap * 16 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[4 * t + e], b[i][e], (t == 0 && e == 0) ? b2r : acc[i], 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < G; ++i) b[i] = bn[i];
+    }
+    if constexpr (G == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else if constexpr (G == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m0 + i * step) + li;
@@ -153,23 +179,35 @@ __device__ __forceinline__ void espcn_f3_group(const EspcnArgs& a, const float* 
         const int tt = t < n3 ? t : 0;
         const int r = tt / tw, c = tt - r * tw;
         la[i] = (r * w2 + c) * kP2 + 4 * kq;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = b3r[e];
     }
+    const f32x4 b3v = {b3r[0], b3r[1], b3r[2], b3r[3]};
+    f32x4 b[G], bn[G];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int i = 0; i < G; ++i) b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i]);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 b[G];
+    for (int t = 0; t < 18; ++t) {
+        if (t + 1 < 18) {
+            const int tap1 = (t + 1) / 2, g1 = (t + 1) % 2;
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap / 3) * w2 + (tap % 3)) * kP2 + 16 * g);
+                bn[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap1 / 3) * w2 + (tap1 % 3)) * kP2 + 16 * g1);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (G >= 3) {
+                if (t == 0 && e == 0) mfma_sub_a_first(acc, b3v, w3r[0], b[0][0], b[1][0], b[2][0], b[G - 1][0]);
+                else mfma_sub_a(acc, w3r[4 * t + e], b[0][e], b[1][e], b[2][e], b[G - 1][e]);
+            } else {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[tap * 8 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[4 * t + e], b[i][e], (t == 0 && e == 0) ? b3v : acc[i], 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < G; ++i) b[i] = bn[i];
+    }
+    if constexpr (G == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else if constexpr (G == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int t = 16 * (m0 + i * step) + li;
@@ -186,9 +224,9 @@ __device__ __forceinline__ void espcn_f3_group(const EspcnArgs& a, const float* 
 template <int NCH3>
 __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* X0 = lds;
-    float* T1 = lds + kX0;
-    float* T2 = T1 + kT1;
+    float* T1 = lds;
+    float* X0 = lds + kT1;
+    float* T2 = lds + kT1;          // (shares the halo's bytes: see kShared)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -223,6 +261,13 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
     float b3r[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) b3r[e] = (16 * ch3 + 4 * kq + e < a.C3) ? a.b3[16 * ch3 + 4 * kq + e] : 0.f;
+    // f2's and f3's weights live in accumulation registers from here on (216 of them: the 256 architectural VGPRs cannot
+    // hold 241 weights AND double-buffered LDS fragments -- round 3's build read every fragment right before its MFMA).
+    // They are defined as "a" values here and consumed by the "a" operands of the asm MFMA statements.
+#pragma unroll
+    for (int i = 0; i < 144; ++i) { const float t = w2r[i]; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w2r[i]) : "v"(t)); }
+#pragma unroll
+    for (int i = 0; i < 72; ++i) { const float t = w3r[i]; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w3r[i]) : "v"(t)); }
     // sub-pixel store: channel ch -> HR row + ch / (3 r), element + ch % (3 r)   (srx_conv_desc.subpixel_r)
     const int rc = 3 * a.r, hr_row = a.W * rc;
     int eo[4];
@@ -297,31 +342,33 @@ extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b
     EspcnArgs a;
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.hr = hr;
     a.N = N; a.H = H; a.W = W; a.r = r; a.C3 = 3 * r * r;
-    // Tile shape: <= 9 x 9, the image cut evenly in each direction; among the cuts that need the fewest rounds of
-    // workgroups over the CUs, the one with the least MFMA work per tile (every phase costs a tile its sub-tiles of 16
-    // pixels: 25 / 144 / 72 MFMAs each, shared by 4 / 2 / W3 waves).  [32,17,17]: 2 x 3 tiles of 9 x 6 = 192 workgroups in
-    // one round instead of 2 x 2 of 9 x 9 = 128.
+    // Tile shape: <= 16 x 16; among all shapes the one with the least MFMA time: rounds of workgroups over the CUs x the
+    // work of one tile (every phase costs a tile its sub-tiles of 16 pixels: 25 / 144 / 72 MFMAs each, shared by 4 / 2 / W3
+    // waves) + a fixed cost per tile (staging, barriers, ramps).  [32,17,17]: 2 x 3 or 2 x 4 tiles per patch = 192 / 256
+    // workgroups in one round (round 2 used 2 x 2 tiles of 9 x 9: 29.5 -> 22.7 us); a 256 x 256 image: 256 tiles of 16 x 16 in
+    // one round (with the 9 x 9 limit of round 3: 841 tiles in four rounds).  The tiling does not change a bit of the result.
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0 || cus > 256) cus = 256;
     const int nch3 = (a.C3 + 15) / 16, waves3 = nch3 == 3 ? 1 : 4 / nch3;
-    long best_rounds = -1, best_cost = 0;
+    long best_cost = -1;
     a.TY = a.TX = kT;
-    for (int ny = (H + kT - 1) / kT; ny <= H && ny <= (H + kT - 1) / kT + 2; ++ny)
-        for (int nx = (W + kT - 1) / kT; nx <= W && nx <= (W + kT - 1) / kT + 2; ++nx) {
-            const int ty = (H + ny - 1) / ny, tx = (W + nx - 1) / nx;
+    for (int ty = 1; ty <= kT && ty <= H; ++ty)
+        for (int tx = 1; tx <= kT && tx <= W; ++tx) {
+            // (only the even cuts: a tile edge that is not ceil(extent / number of tiles) just leaves a smaller last tile)
+            if (ty != (H + (H + ty - 1) / ty - 1) / ((H + ty - 1) / ty) || tx != (W + (W + tx - 1) / tx - 1) / ((W + tx - 1) / tx)) continue;
             const long tiles = (long)N * ((H + ty - 1) / ty) * ((W + tx - 1) / tx);
             const long rounds = (tiles + cus - 1) / cus;
             const long s1 = ((ty + 4) * (tx + 4) + 15) / 16, s2 = ((ty + 2) * (tx + 2) + 15) / 16, s3 = (ty * tx + 15) / 16;
             const long cost = rounds * (25 * s1 + 144 * ((s2 + 1) / 2) + 72 * ((s3 + waves3 - 1) / waves3) + 150);   // (+150: staging, barriers)
-            if (best_rounds < 0 || cost < best_cost) { best_rounds = rounds; best_cost = cost; a.TY = ty; a.TX = tx; }
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; a.TY = ty; a.TX = tx; }
         }
     a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_x = (W + a.TX - 1) / a.TX;
     const long units = (long)N * a.tiles_y * a.tiles_x;
     if (units >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: too many tiles");
     a.units = (int)units;
     const int grid = (int)(units < (long)cus ? units : (long)cus);
-    const size_t lds = (size_t)(kX0 + kT1 + kT2) * 4;
+    const size_t lds = (size_t)(kT1 + kShared) * 4;
     hipError_t e;
     if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1>, a, grid, lds, (hipStream_t)stream);
     else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2>, a, grid, lds, (hipStream_t)stream);

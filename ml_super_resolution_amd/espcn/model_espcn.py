@@ -44,10 +44,11 @@ class EspcnModel(object):
         self._graphs = {}
         # one launch for the whole net while the problem is latency-bound (SRX_ESPCN_FUSED=0: never)
         self.use_single_launch = os.environ.get('SRX_ESPCN_FUSED', '1') != '0'
-        # (measured, round 3, one launch against the three-launch graph: 27 / 52 / 52 us against 69 / 63 / 66 us at 16 k / 28 k /
-        # 37 k LR pixels, level at 46-58 k, behind from 65 k on -- the one-launch kernel's time steps with its rounds of tiles)
-        self.single_launch_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_MAX_PIXELS', '45000'))
-        self.inference_path = ('<= %d LR pixels: ONE launch, the three layers chained through LDS per 9x9 tile with the '
+        # (measured, round 4 -- tiles of up to 16 x 16, LDS reads a block ahead of the MFMAs -- one launch against the three-launch
+        # graph: 28 / 38 / 62 / 89 / 130 us against 67 / 78 / 79 / 102 / 137 us at 16 k / 29 k / 66 k / 90 k / 131 k LR pixels;
+        # behind at 230 k: 213 against 181 us.  Round 3, 9 x 9 tiles: level at 46-58 k pixels, behind from 65 k on.)
+        self.single_launch_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_MAX_PIXELS', '131072'))
+        self.inference_path = ('<= %d LR pixels: ONE launch, the three layers chained through LDS per <= 16x16 tile with the '
                                'sub-pixel store (srx_espcn_forward); larger: f1, f2, f3 with the sub-pixel store fused into '
                                "f3's epilogue, 3 launches%s" % (self.single_launch_max_pixels,
                                                                ' replayed as one HIP graph' if self.use_graph else ', eager'))
@@ -77,7 +78,7 @@ class EspcnModel(object):
         [N,H,W,3] -> [N,H*r,W*r,3] in three launches -- the f3 layer stores straight through the depth-to-space map
         (bit-identical to super_resolve_two_step) -- replayed as ONE HIP graph per input shape: the problem is
         launch-latency-bound (0.57 GFLOP at BASELINE configs[1]).  Small problems (<= single_launch_max_pixels LR
-        pixels) take ONE launch instead: srx_espcn_forward chains the three layers through LDS per 9x9 tile (same
+        pixels) take ONE launch instead: srx_espcn_forward chains the three layers through LDS per <= 16x16 tile (same
         bits).  The returned tensor is a buffer owned by the model and overwritten by the next call."""
         if single_launch is None:
             single_launch = self.use_single_launch and lr_source.shape[0] * lr_source.shape[1] * lr_source.shape[2] <= self.single_launch_max_pixels

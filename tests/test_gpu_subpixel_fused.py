@@ -78,13 +78,16 @@ def test_espcn_inference_paths_agree(n, h, w, r):
 
 
 @pytest.mark.parametrize('n,h,w,r', [(32, 17, 17, 3), (2, 17, 17, 2), (3, 9, 9, 4), (1, 40, 33, 3), (5, 1, 1, 3), (2, 8, 19, 4),
-                                     (1, 10, 10, 3)],
-                         ids=['config2', 'r2', 'r4_one_tile', 'image_ragged_tiles', 'one_pixel', 'r4_ragged', 'tiles_5x5'])
+                                     (1, 10, 10, 3), (1, 236, 250, 3), (2, 160, 180, 2), (1, 200, 240, 4), (300, 13, 15, 3)],
+                         ids=['config2', 'r2', 'r4_one_tile', 'image_ragged_tiles', 'one_pixel', 'r4_ragged', 'tiles_5x5',
+                              'tiles_16x16_ragged', 'r2_tiles_16x15', 'r4_tiles_14x14', 'two_rounds_of_whole_patches'])
 def test_espcn_single_launch_equals_three_launches(n, h, w, r):
-    """srx_espcn_forward (the three layers chained through LDS per <= 9x9 tile, one launch) against the per-layer
+    """srx_espcn_forward (the three layers chained through LDS per <= 16x16 tile, one launch) against the per-layer
     launches: the same products in the same order -> bit-identical; and <= 1e-3 (elementwise bound) against the
     oracle.  Shapes: exactly BASELINE configs[1]; every scaling factor; tiles that do not divide the image; images
-    smaller than the halo."""
+    smaller than the halo; since round 4 images of up to 59 k pixels, which take the largest tiles (16 x 16: the input halo
+    and t2 share their LDS bytes) -- just below the 60 k pixels from which the per-layer route's f1 groups its products
+    differently (conv_pack3.hip) -- and more tiles than CUs."""
     from ml_super_resolution_amd.espcn import model_espcn
     m = model_espcn.EspcnModel(r, device='cuda', seed=200 + r)
     for i in range(3):
@@ -140,7 +143,7 @@ def test_srcnn_single_launch_equals_three_launches(n, h, w):
     assert torch.equal(one, three), float((one - three).abs().max())
     params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
     close(one, O.srcnn_forward(x.cpu().numpy(), params))
-    assert float(one.abs().max()) > 0.05                   # (not a test of zeros)
+    assert float(one.abs().max()) > 1e-3                   # (not a test of zeros; the biases come from the global RNG)
     # the default route (one launch for latency-bound sizes, three otherwise): the same bits either way
     assert torch.equal(m.forward(x), one)
     with pytest.raises(ValueError):
