@@ -391,11 +391,13 @@ def extras(model, dev, stream, x64, y64, px):
     us = hip_event_time_ms(c1, 100, stream) * 1e3
     out['srcnn_c1_us'] = round(us, 2)
     out['srcnn_c1_tflops'] = round(2200e6 / (us * 1e-6) / 1e12, 2)
-    c3 = lambda: sm.forward(img, single_launch=False)
+    c3 = lambda: sm.forward(img, single_launch=True)
     for _ in range(5):
         c3()
-    out['srcnn_c1_three_launches_us'] = round(hip_event_time_ms(c3, 100, stream) * 1e3, 2)
-    out['srcnn_c1_path'] = 'one launch: 9-1-5 chained through LDS per 15x15 output tile (srx_srcnn_forward), bit-identical to the three launches'
+    out['srcnn_c1_one_launch_us'] = round(hip_event_time_ms(c3, 100, stream) * 1e3, 2)
+    out['srcnn_c1_path'] = ('three launches: 9x9 3->64 on conv_pack3_kernel, 1x1 64->32, 5x5 32->3 on conv_kwrows_kernel (the default route '
+                            'for single images); srcnn_c1_one_launch_us: the three layers chained through LDS per 15x15 output tile '
+                            '(srx_srcnn_forward, the route for batches of small patches)')
     del img, lr
     # -- the small networks' TRAIN steps (espcn/makefile:30-36: batch 64 of 17x17 LR patches, 1.6 M steps; srcnn/srcnn.py:14-16,
     #    28-40: batch 64 of 243x243 crops): forward + loss + backward + Adam replayed as one HIP graph per batch shape

@@ -86,8 +86,12 @@ const char* srx_last_error(void);
  *                for them) run on one workgroup per CU with a double-buffered LDS tile, everything but
  *                the MFMAs done by scalar and memory instructions; all other shapes use the kernels of
  *                path 0;
- *   0            two persistent workgroups per CU, one LDS tile each, for every shape.
- * Same results bit for bit; a tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
+ *   0            two persistent workgroups per CU, one LDS tile each (conv_mfma_kernel), for every shape.
+ * Same results bit for bit on both paths, with ONE exception: path 1 runs SRCNN's 5x5 32 -> 3 layer (from
+ * SRX_KWROWS_MIN_PIXELS = 4096 output pixels) on conv_kwrows_kernel, which adds the kw partial sums of an output in
+ * another order: equal to path 0 to rounding (<= 2e-6 of the output scale).  (Path 1's kernels for the RGB-input 9x9 / 5x5
+ * layers, conv_pack3.hip, keep the order of the products and are bit-identical to path 0.)
+ * A tuning / A-B switch (also: environment SRX_PIPE).  Returns the old value. */
 int srx_set_conv_path(int pipelined);
 
 /* Selects the filter-gradient (Conv2DBackpropFilter) kernel family:

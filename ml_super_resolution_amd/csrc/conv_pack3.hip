@@ -4,9 +4,11 @@
 // MFMAs per 16 pixels and 16 output channels.  Here the LDS pixel is 3 floats, so the 3 KW values (kw, ci) of one filter row are
 // CONSECUTIVE floats and K simply runs along them, 4 at a time: ceil(3 KW / 4) MFMAs per filter row -- 63 instead of 81 for 9x9,
 // 20 instead of 25 for 5x5 -- with the B fragment of MFMA j a plain `ds_read_b32` at (pixel, 4 j + lane's k) and the last
-// MFMA's unused slots weighted zero.  Exact fp32; the products of an output are the same, grouped into MFMAs differently, so
-// the results agree with conv_mfma_kernel to rounding, not bit for bit: the route starts at 60,000 output pixels, beyond the
-// windows of the one-launch ESPCN / SRCNN kernels (whose tests demand bit-equality with the per-layer launches).
+// MFMA's unused slots weighted zero.  Exact fp32.  The products of an output reach its accumulator in the same (kh, kw, ci)
+// order as in conv_mfma_kernel, cut into groups of four at other places -- and the results are BIT-IDENTICAL to that kernel's
+// on every shape tested (tests/test_gpu_ops.py: test_conv_rgb_input_packed_k_route_vs_oracle): v_mfma_f32_16x16x4_f32 adds its
+// four products to the accumulator one after the other in k order, and a zero-weighted slot adds +0.  Thresholds
+// (srx_api.hip): 9x9 from 4,096 output pixels, 5x5 from 60,000 (smaller ESPCN inputs take the one-launch kernel).
 //
 // One workgroup of 8 waves per CU; a tile is 32 output rows x 64 output columns (its input halo: <= 40 x 72 pixels = 34.6 KB);
 // wave = (16-channel chunk, row parity): it walks its rows, four 16-pixel sub-tiles (= the strip's 64 columns) at a time,

@@ -50,6 +50,15 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {        // as act_apply4 (conv_
     return v;
 }
 
+// four MFMAs that share the A operand (a weight in a VGPR), accumulators in VGPRs; the leading s_nop covers a VALU write of
+// any operand right before the statement (hipcc pads no hazards across an inline-asm boundary)
+__device__ __forceinline__ void mfma4_guarded(f32x4 (&c)[4], float w, float b0, float b1, float b2, float b3) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n\t" "v_mfma_f32_16x16x4_f32 %1, %4, %6, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n\t" "v_mfma_f32_16x16x4_f32 %3, %4, %8, %3"
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "v"(w), "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");
+}
+
 __global__ __launch_bounds__(256, 1) void srcnn_fused_kernel(const SrcnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* T1 = lds;
@@ -80,6 +89,12 @@ __global__ __launch_bounds__(256, 1) void srcnn_fused_kernel(const SrcnnArgs a) 
     float b3r[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) b3r[e] = (4 * kq + e < 3) ? a.b3[4 * kq + e] : 0.f;
+    const f32x4 b3v = {b3r[0], b3r[1], b3r[2], b3r[3]};
+    // f3's weights live in accumulation registers from here on: 297 weights do not fit the 256 architectural VGPRs -- round 3's
+    // build kept the overflow in AGPRs behind v_accvgpr_read copies and read every LDS fragment right before its MFMA.  They are
+    // defined as "a" values here and consumed by the "a" operands of the asm MFMA statements of the f3 phase.
+#pragma unroll
+    for (int i = 0; i < 200; ++i) { const float t = w3r[i]; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w3r[i]) : "v"(t)); }
 
     for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
         const int tx_i = u % a.tiles_x, t2_ = u / a.tiles_x;
@@ -112,16 +127,22 @@ __global__ __launch_bounds__(256, 1) void srcnn_fused_kernel(const SrcnnArgs a) 
                 la[i] = (r * w0 + c) * 4 + kq;
                 acc[i] = b1r;
             }
+            // (the LDS reads of tap t + 1 come before the MFMAs of tap t)
+            float b[4], bn[4];
 #pragma unroll
-            for (int kh = 0; kh < 9; ++kh)
+            for (int i = 0; i < 4; ++i) b[i] = X0[la[i]];
 #pragma unroll
-                for (int kw = 0; kw < 9; ++kw) {
-                    float b[4];
+            for (int t = 0; t < 81; ++t) {
+                if (t + 1 < 81) {
+                    const int kh1 = (t + 1) / 9, kw1 = (t + 1) % 9;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) b[i] = X0[la[i] + (kh * w0 + kw) * 4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[kh * 9 + kw], b[i], acc[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) bn[i] = X0[la[i] + (kh1 * w0 + kw1) * 4];
                 }
+                mfma4_guarded(acc, w1r[t], b[0], b[1], b[2], b[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = bn[i];
+            }
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 16 * (s0 + i) + li;
@@ -140,16 +161,22 @@ __global__ __launch_bounds__(256, 1) void srcnn_fused_kernel(const SrcnnArgs a) 
                 la[i] = (t < n1 ? t : 0) * kP1 + 4 * kq;
                 acc[i] = b2r;
             }
+            f32x4 b[4], bn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i]);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 b[4];
+                if (g + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + 16 * g);
+                    for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const f32x4*>(T1 + la[i] + 16 * (g + 1));
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[4 * g + e], b[i][e], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = bn[i];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -170,23 +197,29 @@ __global__ __launch_bounds__(256, 1) void srcnn_fused_kernel(const SrcnnArgs a) 
                 const int tt = t < n3 ? t : 0;
                 const int r = tt / tw, c = tt - r * tw;
                 la[i] = (r * w1 + c) * kP2 + 4 * kq;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][e] = b3r[e];
             }
+            // asm MFMA statements (weights in accumulation registers, the first one defines the accumulators with C = bias);
+            // the fragments of block t + 1 are read before the MFMAs of block t
+            f32x4 b[4], bn[4];
 #pragma unroll
-            for (int tap = 0; tap < 25; ++tap)
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i]);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    f32x4 b[4];
+            for (int t = 0; t < 50; ++t) {
+                if (t + 1 < 50) {
+                    const int tap1 = (t + 1) / 2, g1 = (t + 1) % 2;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        b[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap / 5) * w1 + (tap % 5)) * kP2 + 16 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[tap * 8 + 4 * g + e], b[i][e], acc[i], 0, 0, 0);
+                        bn[i] = *reinterpret_cast<const f32x4*>(T2 + la[i] + ((tap1 / 5) * w1 + (tap1 % 5)) * kP2 + 16 * g1);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (t == 0 && e == 0) mfma_sub_a_first(acc, b3v, w3r[0], b[0][0], b[1][0], b[2][0], b[3][0]);
+                    else mfma_sub_a(acc, w3r[4 * t + e], b[0][e], b[1][e], b[2][e], b[3][e]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = bn[i];
+            }
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
             if (kq == 0) {       // lane group 0 holds output channels 0..3: three of them exist
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -39,7 +39,14 @@ Knobs read_knobs() {
     k.wgrad_lin = env_int("SRX_WGRAD_LIN", 1);
     k.wgrad_pipe = env_int("SRX_WGRAD_PIPE", 1);
     k.wgrad_pipe_strip = env_int("SRX_WGRAD_PIPE_STRIP", 1);   // 0: column-strip filter gradients on the two-workgroup kernel (A/B)
-    k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 60000);   // 5x5 32->3 on conv_kwrows_kernel from this many output pixels (negative: never)
+    // SRCNN's forward layers on their own kernels (5x5 32->3: conv_kwrows_kernel; 9x9 3->64: conv_pack3_kernel) from this many
+    // output pixels (negative: never).  Round 4 started them at 60,000; timed against conv_mfma_kernel they win from the
+    // smallest images on (one 100 x 100 image: level; 170 x 170: 42 against 73 us for the three layers)
+    k.kwrows_min_pixels = env_int("SRX_KWROWS_MIN_PIXELS", 4096);
+    // ESPCN's 5x5 3->64 on conv_pack3_kernel, 3x3 32->27 on conv_rows3x3_kernel (from 150,000), and the 5x5 32->3 filter
+    // gradient on wgrad_kwcols_kernel: from this many output pixels (below: the one-launch ESPCN kernel's window and the
+    // training patches, measured on the older kernels only)
+    k.big_route_min_pixels = env_int("SRX_BIG_ROUTE_MIN_PIXELS", 60000);
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
     k.wgrad_pack3 = env_int("SRX_WGRAD_PACK3", 1);             // 0: RGB-input 9x9 / 5x5 filter gradients on the cursor kernel's 4-channel rows (A/B)
@@ -318,11 +325,14 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
             return SRX_OK;
         }
     }
-    // SRCNN's 5x5 32 -> 3 reconstruction layer on large inputs: (kw, co) pairs as the MFMA's rows -- see conv_kwrows.hip.
-    // Results agree with the kernels below to rounding (another summation order), so the route starts beyond the window
-    // of the one-launch SRCNN kernel, whose tests demand bit-equality with these per-layer launches.
-    if (knobs().kwrows_min_pixels >= 0 && (launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err) ||
-                                           launch_conv_pack3(k, a, knobs().kwrows_min_pixels, s, &err))) {     // (RGB-input 9x9 / 5x5: conv_pack3.hip)
+    // SRCNN's 5x5 32 -> 3 reconstruction layer: (kw, co) pairs as the MFMA's rows -- see conv_kwrows.hip; its 9x9 3 -> 64 and
+    // ESPCN's 5x5 3 -> 64: (kw, ci) along K -- conv_pack3.hip (bit-identical to the kernels below: same order of the products).
+    // conv_kwrows_kernel's results agree with the kernels below to rounding (the kw partial sums are added in another order);
+    // the one-launch SRCNN kernel is bit-identical to the kernels below.
+    // (srx_set_conv_path(0) keeps every shape on the conv_mfma_kernel family: the reference point of the bit-identity tests.)
+    if (g_use_pipe && knobs().kwrows_min_pixels >= 0 &&
+        (launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err) ||                                      // (RGB-input 9x9 / 5x5: conv_pack3.hip)
+         launch_conv_pack3(k, a, k.kh == 9 ? knobs().kwrows_min_pixels : knobs().big_route_min_pixels, s, &err))) {
         if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
         return SRX_OK;
     }
@@ -366,7 +376,7 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     }
     // 3x3 layers of 17..32 output channels that the pipelined family did not take, on large inputs (ESPCN's f2 / f3 on whole
     // images): one workgroup of 8 waves per CU, see conv_rows3x3.hip.  Bit-identical to the kernels below.
-    if (g_use_pipe && knobs().kwrows_min_pixels >= 0 && launch_conv_rows3x3(k, a, knobs().kwrows_min_pixels, s, &err)) {
+    if (g_use_pipe && knobs().big_route_min_pixels >= 0 && launch_conv_rows3x3(k, a, knobs().big_route_min_pixels, s, &err)) {
         if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
         return SRX_OK;
     }
@@ -585,11 +595,10 @@ int srx_conv2d_bwd_filter_partials(const srx_conv_desc* d, const float* x, const
         int n1 = 0;
         if (launch_wgrad_1x1(k, a, p.grid, &n1, s, &err)) { wdone = true; wgrid = n1; }
     }
-    // SRCNN's 5x5 32 -> 3 layer on large inputs: (kw, co) pairs as the MFMA's columns (conv_kwrows.hip), from the same size on as
-    // the forward route
-    if (!wdone && knobs().kwrows_min_pixels >= 0 && wpath >= 1 && !s2) {
+    // SRCNN's 5x5 32 -> 3 layer on large inputs: (kw, co) pairs as the MFMA's columns (conv_kwrows.hip)
+    if (!wdone && knobs().big_route_min_pixels >= 0 && wpath >= 1 && !s2) {
         int n1 = 0;
-        if (launch_wgrad_kwcols(k, a, p.grid, knobs().kwrows_min_pixels, &n1, s, &err)) { wdone = true; wgrid = n1; }
+        if (launch_wgrad_kwcols(k, a, p.grid, knobs().big_route_min_pixels, &n1, s, &err)) { wdone = true; wgrid = n1; }
     }
     // 41-pixel rows (the VDSR patch of BASELINE's metric): exact rows, one 31-step window per 3-row unit (wgrad_rows_full_kernel)
     if (!wdone && use_wpipe && knobs().wgrad_rows_full && lin_ok && d->KH == 3 && d->KW == 3 && d->Cin == 64 && d->Cout == 64 && OW == 41 && d->W == 41 &&

@@ -83,11 +83,13 @@ class SrcnnModel(object):
             truncated_normal_(self.stack.kernel(i), 0.001, gen)    # srcnn.py:84; biases zero
         self.placeholders = {}
         self.use_single_launch = os.environ.get('SRX_SRCNN_FUSED', '1') != '0'
-        # one round of 15 x 15 tiles over the 256 CUs; below ~36 tiles the three launches' latency is the shorter chain
-        # (measured, scripts/time_srcnn.py: 1 x 243^2 66 vs 90 us, 64 x 33^2 50 vs 79 us; 1 x 256^2 -- 289 tiles, two rounds --
-        # 119 vs 93 us; 1 x 33^2 49 vs 40 us)
+        # ONE launch (srx_srcnn_forward) for batches of small patches only.  Measured (scripts/time_srcnn.py, round 4): since the
+        # per-layer route has its own kernels for the 9x9 3->64 and 5x5 32->3 layers, three launches win on single images of every
+        # size (1 x 243^2: 52 against 58 us; 1 x 170^2: 43 against 58 -- a 15 x 15 tile costs the one-launch kernel ~55 us however few
+        # of them there are); the one launch wins on many small patches (64 x 33^2: 46 against 54 us; 128 x 33^2: level).
         self.single_launch_max_pixels = int(os.environ.get('SRX_SRCNN_FUSED_MAX_PIXELS', '57600'))
         self.single_launch_min_pixels = int(os.environ.get('SRX_SRCNN_FUSED_MIN_PIXELS', '8000'))
+        self.single_launch_max_patch = int(os.environ.get('SRX_SRCNN_FUSED_MAX_PATCH', '1024'))     # output pixels per image
 
     def crop_side(self):
         f = self.flags
@@ -103,15 +105,17 @@ class SrcnnModel(object):
 
     def forward(self, sd_images, keep=False, single_launch=None):
         """[N,S,S,3] bicubic-interpolated input -> [N,S-12,S-12,3] (VALID 9-1-5).
-        Inference (keep=False) of latency-bound sizes -- `single_launch_min_pixels` .. `single_launch_max_pixels` output pixels: BASELINE configs[0]'s
-        one image is 231 x 231 = 256 tiles, one per CU -- runs as ONE launch that chains the three layers through LDS
-        (srx_srcnn_forward, bit-identical to the three launches); larger problems and training keep the per-layer
-        launches, whose activations backward needs."""
+        Three launches (BASELINE configs[0]'s one 243 x 243 image: conv_pack3_kernel, the 1x1 layer, conv_kwrows_kernel).
+        Inference (keep=False) on batches of small patches -- at most `single_launch_max_patch` output pixels per image,
+        `single_launch_min_pixels` .. `single_launch_max_pixels` in all -- runs as ONE launch that chains the three layers
+        through LDS (srx_srcnn_forward; bit-identical to the three launches on conv path 0, equal to rounding on the default
+        path); training keeps the per-layer launches, whose activations backward needs."""
         f = self.flags
         if single_launch is None:
             n, h, w, _ = sd_images.shape
             single_launch = (self.use_single_launch and not keep and sd_images.is_cuda and (f.srcnn_f1, f.srcnn_f2, f.srcnn_f3) == (9, 1, 5)
                              and (f.srcnn_n1, f.srcnn_n2) == (64, 32) and h >= 13 and w >= 13
+                             and (h - 12) * (w - 12) <= self.single_launch_max_patch
                              and self.single_launch_min_pixels <= n * (h - 12) * (w - 12) <= self.single_launch_max_pixels)
         if single_launch:
             params = [(self.stack.kernel(i), self.stack.bias(i)) for i in range(3)]

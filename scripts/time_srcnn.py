@@ -24,7 +24,8 @@ def timed(fn):
     for _ in range(100): fn()
     e.record(); e.synchronize()
     return s.elapsed_time(e) / 100 * 1e3
-for n, hw in ((1, 243), (1, 256), (2, 243), (4, 243), (16, 243), (1, 33), (64, 33)):
+shapes = [(int(a), int(b)) for a, b in zip(sys.argv[1::2], sys.argv[2::2])] or [(1, 243), (1, 256), (2, 243), (4, 243), (16, 243), (1, 33), (64, 33)]
+for n, hw in shapes:
     x = rnd(n, hw, hw, 3)
     us = timed(lambda: fwd(x))
     us1 = timed(lambda: ops.srcnn_forward(x, params))

@@ -535,30 +535,38 @@ def test_stride2_argument_errors(ops):
     assert rc != 0
 
 
-@pytest.mark.parametrize('shape', [(1, 300, 260, 'VALID', 'tanh'), (2, 190, 171, 'SAME', None), (1, 263, 250, 'VALID', 'relu'), (3, 160, 130, 'SAME', 'tanh')],
-                         ids=['1x300x260_valid', '2x190x171_same', '1x263x250_valid', '3x160x130_same'])
+@pytest.mark.parametrize('shape', [(1, 300, 260, 'VALID', 'tanh'), (2, 190, 171, 'SAME', None), (1, 263, 250, 'VALID', 'relu'), (3, 160, 130, 'SAME', 'tanh'),
+                                   (2, 60, 70, 'VALID', 'tanh'), (1, 70, 64, 'SAME', 'relu'), (5, 33, 40, 'VALID', None), (1, 235, 235, 'VALID', 'tanh'),
+                                   (1, 69, 61, 'SAME', 'tanh')],
+                         ids=['1x300x260_valid', '2x190x171_same', '1x263x250_valid', '3x160x130_same', '2x60x70_valid', '1x70x64_same', '5x33x40_valid',
+                              'srcnn_config1_t2', '1x69x61_same_just_above_the_threshold'])
 def test_conv_5x5_32_to_3_kw_rows_route_vs_oracle(shape, ops):
-    """SRCNN's reconstruction layer (srcnn/srcnn.py:122-130: 5x5 32 -> 3, tanh) on inputs of more than 60,000 output pixels
+    """SRCNN's reconstruction layer (srcnn/srcnn.py:122-130: 5x5 32 -> 3, tanh) on inputs of at least 4,096 output pixels
     runs conv_kwrows_kernel: (kw, co) pairs as the MFMA's rows, the kw partial sums added through LDS.  Against the
     oracle: VALID (the reference's geometry) and SAME (zero padding inside the staged tile), strips narrower than 60
-    columns, tiles shorter than 8 rows, several images; and against the 16-output-channel MFMA kernel the smaller
-    problems stay on (same products, another summation order: agreement to rounding)."""
+    columns, tiles shorter than 8 rows, several images, BASELINE configs[0]'s own shape (t2 of one 243 x 243 image), batches
+    of small patches; and against the 16-output-channel MFMA kernel (conv path 0: same products, another summation order:
+    agreement to rounding)."""
     N, H, W, pad, act = shape
     rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
     x = rng.uniform(-1, 1, (N, H, W, 32)).astype(np.float32)
     w = rng.normal(0, 1.0 / np.sqrt(25 * 32), (5, 5, 32, 3)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, (3,)).astype(np.float32)
     ref = O.c_conv2d_fwd(x, w, b, pad, act)
-    assert ref.shape[0] * ref.shape[1] * ref.shape[2] > 60000
+    assert ref.shape[0] * ref.shape[1] * ref.shape[2] >= 4096
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = ops.conv2d_fwd(xd, wd, bd, pad, act)
     close(y, ref)
     assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, pad, act))
-    # one image of the batch alone is below the threshold: the MFMA kernel
-    y1 = ops.conv2d_fwd(xd[:1, :120].contiguous(), wd, bd, pad, act)
-    close(y1, O.c_conv2d_fwd(x[:1, :120], w, b, pad, act))
-    rows = y1.shape[1] - (0 if pad == 'VALID' else 2)       # (SAME: the cut image's last rows see other padding)
-    assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0 = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    close(y0, ref)
+    assert (y - y0).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+    assert not torch.equal(y, y0) or N * H * W < 8000        # (another kernel did run: the summation orders differ somewhere)
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1, 64, 32), (1, 3, 7, 64, 64), (2, 25, 25, 64, 32), (3, 33, 41, 32, 32), (1, 235, 235, 64, 32), (5, 64, 67, 64, 64),
@@ -626,29 +634,39 @@ def test_wgrad_5x5_32_to_3_kw_columns_route_vs_oracle(shape, ops):
     assert (dw0.double() - dw.double()).abs().max().item() <= 4e-6 * dw.abs().max().item()
 
 
-@pytest.mark.parametrize('shape', [(1, 300, 260, 9, 'VALID', 'relu'), (2, 190, 171, 5, 'SAME', 'tanh'), (1, 263, 250, 9, 'SAME', None), (3, 170, 131, 5, 'VALID', 'relu')],
-                         ids=['1x300x260_k9_valid', '2x190x171_k5_same', '1x263x250_k9_same', '3x170x131_k5_valid'])
+@pytest.mark.parametrize('shape', [(1, 300, 260, 9, 'VALID', 'relu'), (2, 190, 171, 5, 'SAME', 'tanh'), (1, 263, 250, 9, 'SAME', None), (3, 170, 131, 5, 'VALID', 'relu'),
+                                   (1, 80, 90, 9, 'VALID', 'relu'), (4, 33, 33, 9, 'SAME', None), (2, 60, 57, 9, 'VALID', 'tanh'), (1, 243, 243, 9, 'VALID', 'relu'),
+                                   (64, 33, 33, 9, 'VALID', 'relu')],
+                         ids=['1x300x260_k9_valid', '2x190x171_k5_same', '1x263x250_k9_same', '3x170x131_k5_valid', '1x80x90_k9_valid', '4x33x33_k9_same',
+                              '2x60x57_k9_valid', 'srcnn_config1', 'srcnn_train_patches'])
 def test_conv_rgb_input_packed_k_route_vs_oracle(shape, ops):
-    """The RGB-input layers (SRCNN 9x9 3 -> 64, srcnn/srcnn.py:100-109; ESPCN 5x5 3 -> 64, espcn/espcn/model_espcn.py:30-38) on
-    inputs of more than 60,000 output pixels: conv_pack3_kernel, 3-float LDS pixels with (kw, ci) running along the MFMA's K
+    """The RGB-input layers (SRCNN 9x9 3 -> 64, srcnn/srcnn.py:100-109, from 4,096 output pixels; ESPCN 5x5 3 -> 64,
+    espcn/espcn/model_espcn.py:30-38, from 60,000): conv_pack3_kernel, 3-float LDS pixels with (kw, ci) running along the MFMA's K
     (63 / 20 MFMAs per 16 pixels instead of 81 / 25).  VALID and SAME (zero padding inside the tile), strips narrower than 64
-    columns, tiles shorter than 32 rows; against the oracle, deterministic, and beside the 4-float-pixel MFMA kernel on a cut
-    of the input below the threshold (same products, other grouping: agreement to rounding)."""
+    columns, tiles shorter than 32 rows, BASELINE configs[0]'s own shape, the reference's training patches; against the oracle,
+    deterministic, and BIT-IDENTICAL to the 4-float-pixel MFMA kernels of conv path 0: the products of an output reach the
+    accumulator in the same (kh, kw, ci) order, only cut into groups of four at other places, and v_mfma_f32_16x16x4_f32 adds
+    its four products one after the other (measured here: no shape of this list differs in a single bit; a zero-weighted
+    pad slot adds +0)."""
     N, H, W, k, pad, act = shape
     rng = np.random.default_rng(zlib.crc32(repr(('pack3',) + shape).encode()))
     x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
     w = rng.normal(0, 1.0 / np.sqrt(k * k * 3), (k, k, 3, 64)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, (64,)).astype(np.float32)
     ref = O.c_conv2d_fwd(x, w, b, pad, act)
-    assert ref.shape[0] * ref.shape[1] * ref.shape[2] > 60000
+    assert ref.shape[0] * ref.shape[1] * ref.shape[2] >= (4096 if k == 9 else 60000)
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = ops.conv2d_fwd(xd, wd, bd, pad, act)
     close(y, ref)
     assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, pad, act))
-    y1 = ops.conv2d_fwd(xd[:1, :100].contiguous(), wd, bd, pad, act)          # below the threshold: conv_mfma_kernel
-    close(y1, O.c_conv2d_fwd(x[:1, :100], w, b, pad, act))
-    rows = y1.shape[1] - (0 if pad == 'VALID' else k // 2)
-    assert (y[:1, :rows] - y1[:, :rows]).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0 = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    close(y0, ref)
+    assert torch.equal(y, y0), float((y - y0).abs().max())
 
 
 @pytest.mark.parametrize('shape', [(2, 11, 13, 7, 7, 8, 5, 'SAME'), (1, 9, 9, 4, 4, 3, 16, 'SAME'), (2, 10, 12, 2, 2, 64, 64, 'VALID'), (1, 20, 20, 7, 7, 32, 48, 'VALID'),

@@ -140,11 +140,25 @@ def test_srcnn_single_launch_equals_three_launches(n, h, w):
     one = m.forward(x, single_launch=True).clone()
     three = m.forward(x, single_launch=False).clone()
     assert one.shape == (n, h - 12, w - 12, 3)
-    assert torch.equal(one, three), float((one - three).abs().max())
+    # bit-identical to the per-layer launches of conv path 0 (conv_mfma_kernel for every layer); the default path runs the
+    # 9x9 and 5x5 layers on kernels that group the products differently (conv_pack3 / conv_kwrows, from 4096 output pixels)
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        three0 = m.forward(x, single_launch=False).clone()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(one, three0), float((one - three0).abs().max())
+    assert float((one - three).abs().max()) <= 2e-6 * max(1.0, float(three.abs().max()))
+    if n * (h - 12) * (w - 12) < 4096:
+        assert torch.equal(one, three)
     params = [(m.stack.kernel(i).cpu().numpy(), m.stack.bias(i).cpu().numpy()) for i in range(3)]
     close(one, O.srcnn_forward(x.cpu().numpy(), params))
     assert float(one.abs().max()) > 1e-3                   # (not a test of zeros; the biases come from the global RNG)
-    # the default route (one launch for latency-bound sizes, three otherwise): the same bits either way
-    assert torch.equal(m.forward(x), one)
+    # the default route: one launch for batches of small patches, the three launches otherwise
+    dflt = m.forward(x)
+    assert torch.equal(dflt, one) or torch.equal(dflt, three)
+    if (h - 12) * (w - 12) > 1024:
+        assert torch.equal(dflt, three)
     with pytest.raises(ValueError):
         ops.srcnn_forward(x[:, :12], [(m.stack.kernel(i), m.stack.bias(i)) for i in range(3)])
