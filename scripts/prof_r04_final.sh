@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 final evidence set on the final binary (after wgrad_rows_full_kernel, the SRCNN training kernels, conv_pack3, conv_rows3x3
-# and the inlined branch-free tanh): bench kernel stats + line, recipe kernel stats, SRCNN train kernel stats, HBM counters of the
+# Round-4 final evidence set on the final binary (after wgrad_rows_full_kernel, the SRCNN training kernels, conv_pack3, conv_rows3x3, the
+# two-chunk pipelined strips, the 16x16-tile ESPCN kernel and the inlined branch-free tanh): bench kernel stats + line, recipe kernel stats, SRCNN train kernel stats, HBM counters of the
 # dominant kernel (traffic.json), MFMA-busy counters of the VDSR body trio, the timing scripts.
 set -e
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
@@ -22,3 +22,8 @@ python3 scripts/time_layer.py 256 41 41 64 41 41 2>&1 | grep -v amdgpu.ids > gpu
 SRX_WGRAD_ROWS_FULL=0 python3 scripts/time_layer.py 256 41 41 64 41 41 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_time_layer_41.txt
 python3 scripts/time_srcnn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_time_srcnn.txt
 python3 scripts/time_espcn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_time_espcn.txt
+scripts/prof_stats.sh r04_espcn_image python3 scripts/time_espcn_image.py
+scripts/prof_pmc.sh r04_espcn_image "$MF" python3 scripts/time_espcn_image.py
+python3 scripts/time_espcn_train.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_time_espcn_train.txt
+python3 scripts/time_layer.py 64 128 128 4 512 512 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_time_layer_strip.txt
+python3 bench.py > gpurun_out/r04_bench_line.json 2> gpurun_out/r04_bench_line.err
