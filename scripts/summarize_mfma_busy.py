@@ -16,17 +16,18 @@ RND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOWN = {  # kernel-name fragment -> algorithmic FLOPs per launch of the profiled script
     ('conv', 'conv_pipe_kernel<3, 3, 64, 4, false, 0>'): 73728.0 * 430336, ('conv', 'conv_pipe_kernel<3, 3, 64, 4, true, 1>'): 73728.0 * 430336,
-    ('conv', 'wgrad_pipe_kernel<3, 3, 64, 4>'): 73728.0 * 430336,
+    ('conv', 'wgrad_pipe_kernel<3, 3, 64, 4>'): 73728.0 * 430336, ('conv', 'wgrad_rows_full_kernel<3, 3, 64, 4, 41>'): 73728.0 * 430336,
     ('strip', 'conv_pipe_strip_kernel<3, 3, 64, 4, false, 0>'): 73728.0 * 4 * 512 * 512, ('strip', 'conv_pipe_strip_kernel<3, 3, 64, 4, true, 1>'): 73728.0 * 4 * 512 * 512,
     ('strip', 'wgrad_lin_strip_kernel<3, 3, 64, 4, 2>'): 73728.0 * 4 * 512 * 512,
     ('strip', 'wgrad_rows_strip_kernel<3, 3, 64, 4, true>'): 73728.0 * 4 * 512 * 512, ('strip', 'wgrad_rows_strip_kernel<3, 3, 64, 4, false>'): 73728.0 * 4 * 512 * 512,
 }
 WHAT = {'conv': 'scripts/prof_conv.py 5 all (VDSR body layer 3x3 64->64 at 256x41x41, back to back)',
         'wide': 'scripts/time_wide.py 4 512 (VGG-19 wide layers, 4 x 512^2; averages over the six layer shapes)',
+        'espcn_image': 'scripts/time_espcn_image.py (ESPCN 3x on whole images, 128^2 ... 720 x 1280 LR: each kernel averaged over all the sizes it ran at)',
         'strip': 'scripts/time_layer.py 4 512 512 (3x3 64->64 on 4 x 512^2: column strips)' if RND == 'r03' else
                  'scripts/time_layer.py 64 128 128 (3x3 64->64 at the reference recipe\'s 64 x 128^2: column strips; same pixel count as 4 x 512^2)'}
 out = [['run', 'kernel', 'dispatches', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_BUSY_CU_CYCLES', 'mfma_util', 'useful_util', 'util_resident', 'what']]
-for run in ('conv', 'wide', 'strip'):
+for run in ('conv', 'wide', 'strip', 'espcn_image'):
     fs = glob.glob(os.path.join(ROOT, 'gpurun_out', '%s_%s_SQ_VALU_MFMA_BUSY_CYCLES+*.csv' % (RND, run)))
     if not fs:
         continue

@@ -1,5 +1,6 @@
 """GPU parity tests of the C-ABI ops (libsrx.so) against the CPU oracle and the committed
 golden vectors.  Tolerance: 1e-3 relative fp32 (north_star); the sub-pixel maps are bit-exact."""
+import os
 import zlib
 
 import numpy as np
@@ -566,7 +567,8 @@ def test_conv_5x5_32_to_3_kw_rows_route_vs_oracle(shape, ops):
         _lib.lib().srx_set_conv_path(old)
     close(y0, ref)
     assert (y - y0).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
-    assert not torch.equal(y, y0) or N * H * W < 8000        # (another kernel did run: the summation orders differ somewhere)
+    if int(os.environ.get('SRX_KWROWS_MIN_PIXELS', '4096')) >= 0 and os.environ.get('SRX_PIPE', '1') != '0':
+        assert not torch.equal(y, y0) or N * H * W < 8000    # (another kernel did run: the summation orders differ somewhere)
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1, 64, 32), (1, 3, 7, 64, 64), (2, 25, 25, 64, 32), (3, 33, 41, 32, 32), (1, 235, 235, 64, 32), (5, 64, 67, 64, 64),
