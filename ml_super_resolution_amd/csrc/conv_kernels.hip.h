@@ -960,18 +960,21 @@ struct PipePend {      // a finished group waiting for its epilogue
 };
 struct PipeEpi {
     int lo, lo2;       // wave-uniform clamps
-    int cout4;         // Cout * 4
-    int sh, rowb;      // column strips: log2(sub-tiles per strip row), bytes of one output row
+    int cout4;         // Cout * 4   (AUX 4: the bytes from one LR pixel to the next inside an HR row, 3 r * 4)
+    int sh, rowb;      // column strips: log2(sub-tiles per strip row), bytes of one output row (AUX 4: of r HR rows)
+    int vo1, vo2, vo3; // AUX 4 only, PER LANE: byte offsets of the lane's output elements 1..3 (element 0: vst)
 };
-// AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add, 3 no aux operand + tanh (ESPCN's f2 on whole images)
+// AUX (template): 0 no aux operand, 1 ReluGrad mask (dgrad), 2 residual add, 3 no aux operand + tanh (ESPCN's f2 on whole images),
+// 4 no aux operand, no activation, stored through the sub-pixel map (ESPCN's f3 on whole images; column strips only)
 template <int AUX>
 __device__ __forceinline__ PipeEpi pipe_epi_setup(const ConvArgs& a) {
     PipeEpi e;
     e.lo = (a.act == ACT_RELU) ? 0 : (int)0x80000000;
     e.lo2 = (AUX == 2 && a.post_relu) ? 0 : (int)0x80000000;
-    e.cout4 = a.Cout * 4;
+    e.cout4 = (AUX == 4) ? 3 * a.d2s_r * 4 : a.Cout * 4;
     e.sh = (a.TW >= 32) ? 1 : 0;
-    e.rowb = a.OW * a.Cout * 4;
+    e.rowb = (AUX == 4) ? a.d2s_r * (a.OW * a.d2s_r * 3) * 4 : a.OW * a.Cout * 4;
+    e.vo1 = e.vo2 = e.vo3 = 0;
     return e;
 }
 __device__ __forceinline__ f32x4 clamp_lo4(f32x4 v, int lo) {
@@ -1017,11 +1020,21 @@ __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd,
         }
     } else if (AUX == 2) {
         v = clamp_lo4(clamp_lo4(v, ep.lo) + pd.aux[AUX ? i : 0], ep.lo2);
-    } else {
+    } else if (AUX != 4) {
         v = clamp_lo4(v, ep.lo);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), pd.yrs, vst,
-                                           subtile_soffset<Z>(pd.m_first + i * NPART, i < pd.gs, ep), 0);
+    const int so = subtile_soffset<Z>(pd.m_first + i * NPART, i < pd.gs, ep);
+    if (AUX == 4) {
+        // channel c of LR pixel (h, w) is HR element (h r + c / (3 r), 3 r w + c % (3 r)): four 4-byte stores per lane, their
+        // per-lane offsets fixed for the kernel (channels past the layer's 3 r^2: out of range)
+        float f0 = v[0], f1 = v[1], f2 = v[2], f3 = v[3];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(f0), pd.yrs, vst, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(f1), pd.yrs, ep.vo1, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(f2), pd.yrs, ep.vo2, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(f3), pd.yrs, ep.vo3, so, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), pd.yrs, vst, so, 0);
+    }
 }
 
 // One k-step (4 input channels of one tap) for G accumulators: G MFMAs, weight from an AGPR.
@@ -1265,7 +1278,7 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
     // ---- per-lane constants
     const int voff_lane = tid * 16;                         // image bytes of (slot sp, chunk c4) inside a pass
     const int wl_lane = (sp * PS + 4 * c4) * 4;             // the same inside LDS
-    const int vst = (cb < a.Cout) ? (li * a.Cout + cb) * 4 : kOobOffset;   // output bytes inside a sub-tile
+    int vst = (cb < a.Cout) ? (li * a.Cout + cb) * 4 : kOobOffset;   // output bytes inside a sub-tile
     const int tlane = (((lane >> 2) + 16 * part) * PS + CINP + (lane & 3)) * 4;   // this lane's table entry of sub-tile `part`
     StageGeo SG;
     const int JP = (a.RS + PPP - 1) / PPP;
@@ -1275,7 +1288,17 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
     SG.m_first = uniform64(__ballot(sp >= a.pad_l));
     SG.m_last = uniform64(__ballot((JP - 1) * PPP + sp < a.RS));
     SG.m_row = SG.m_last;
-    const PipeEpi ep = pipe_epi_setup<AUX>(a);
+    PipeEpi ep = pipe_epi_setup<AUX>(a);
+    if constexpr (AUX == 4) {
+        const int rc = 3 * a.d2s_r, hr_row = a.OW * a.d2s_r * 3;       // floats
+        int vo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cb + e, dy = c / rc;
+            vo[e] = (c < a.Cout) ? (li * rc + dy * hr_row + (c - dy * rc)) * 4 : kOobOffset;
+        }
+        vst = vo[0]; ep.vo1 = vo[1]; ep.vo2 = vo[2]; ep.vo3 = vo[3];
+    }
     const float* auxp = a.mask ? a.mask : a.skip;
 
     // tile descriptor of unit u (wave-uniform)
@@ -1360,9 +1383,12 @@ __device__ __forceinline__ void conv_pipe_body(const ConvArgs& a) {
 
         PipeUnit un;
         const int npx = th * (Z ? a.TW : a.OW);
-        const size_t unit_off = (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout;
+        // (AUX 4: the unit's HR elements: r HR rows of 3 r OW floats per LR row, 3 r floats per LR pixel)
+        const size_t unit_off = (AUX == 4) ? (((size_t)n * a.OH + h) * a.d2s_r * a.OW + ow0) * (size_t)(3 * a.d2s_r)
+                                           : (((size_t)n * a.OH + h) * a.OW + ow0) * a.Cout;
         // (strips: the unit's bytes run from its first pixel to the last pixel of its last row)
-        const int unit_bytes = (Z ? (th - 1) * a.OW + a.TW : npx) * ep.cout4;
+        const int unit_bytes = (AUX == 4) ? ((th * a.d2s_r - 1) * a.OW + a.TW) * ep.cout4
+                                          : (Z ? (th - 1) * a.OW + a.TW : npx) * ep.cout4;
         un.yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + unit_off, 0, unit_bytes, 0x00020000);
         un.auxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((AUX == 1 || AUX == 2) ? auxp + unit_off : a.x), 0,
                                                      (AUX == 1 || AUX == 2) ? unit_bytes : 0, 0x00020000);
@@ -1422,6 +1448,7 @@ __global__ __launch_bounds__(256, 1) void conv_pipe_kernel(const ConvArgs a) {
 template <int KH, int KW, int CINP, int NCH, bool WT, int AUX>
 __global__ __launch_bounds__(256, 1) void conv_pipe_strip_kernel(const ConvArgs a) {
     static_assert(NCH == 4 || NCH == 2, "strip tiles: 64 or 32 output channels");
+    static_assert(AUX != 4 || (!WT && NCH == 2), "sub-pixel store: forward, <= 32 output channels");
     conv_pipe_body<KH, KW, CINP, NCH, WT, AUX, true>(a);
 }
 

@@ -110,6 +110,11 @@ inline hipError_t launch_with_lds(K kernel, const A& a, int grid, size_t lds, hi
             *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 0>, a, grid, lds, s); \
         return true;                                                                                      \
     }
+#define SRX_PIPE_STRIP_CASE_D2S(KH, KW, CINP, NCH)                                                        \
+    if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH && !k.wt && !a.skip && !a.mask && a.d2s_r) { \
+        *err = launch_with_lds(conv_pipe_strip_kernel<KH, KW, CINP, NCH, false, 4>, a, grid, lds, s);     \
+        return true;                                                                                      \
+    }
 #define SRX_WGRAD_LIN_CASE(KH, KW, CINP, NCH, MINW)                                                       \
     if (k.kh == KH && k.kw == KW && k.cinp == CINP && k.nch == NCH) {                                     \
         *err = launch_with_lds(wgrad_lin_kernel<KH, KW, CINP, NCH, MINW>, a, grid, lds, s);               \

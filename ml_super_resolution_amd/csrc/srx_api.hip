@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels, strip_d2s;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -47,6 +47,7 @@ Knobs read_knobs() {
     // gradient on wgrad_kwcols_kernel: from this many output pixels (below: the one-launch ESPCN kernel's window and the
     // training patches, measured on the older kernels only)
     k.big_route_min_pixels = env_int("SRX_BIG_ROUTE_MIN_PIXELS", 60000);
+    k.strip_d2s = env_int("SRX_STRIP_D2S", 1);                 // 0: ESPCN's f3 on wide images stays off the pipelined strip kernel (A/B)
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
     k.wgrad_pack3 = env_int("SRX_WGRAD_PACK3", 1);             // 0: RGB-input 9x9 / 5x5 filter gradients on the cursor kernel's 4-channel rows (A/B)
@@ -353,8 +354,13 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // (32 output channels: forward only, no aux operand, and the one shape with a tanh form of the deferred epilogue -- ESPCN's f2)
     const bool strip2 = npart == 2 && !wt && !a.skip && !a.mask && !a.post_relu && a.Cout == 32 && p.cinp == 64 &&
                         (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_TANH);
-    const bool strip_ok = (epi_ok || strip2) && !a.d2s_r && a.stride == 1 && a.Cin == p.cinp && p.NTX > 1 && (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
-                          p.RS >= ppp && (npart == 1 || strip2) && (a.Cout & 3) == 0 &&
+    // (ESPCN's f3 -- 3x3 32 -> 3 r^2 through the sub-pixel map, no activation -- on the same two-chunk strips: AUX = 4)
+    const bool strip_d2s = knobs().strip_d2s && npart == 2 && !wt && !a.skip && !a.mask && !a.post_relu && a.d2s_r > 0 && a.act == ACT_NONE &&
+                           p.cinp == 32 && a.Cout > 16 && a.Cout <= 32 && k.kh == 3 && k.kw == 3 &&
+                           (long)a.OH * a.d2s_r * a.OW * a.d2s_r * 3 * 4 < (1L << 31) - 64;
+    const bool strip_ok = (epi_ok || strip2 || strip_d2s) && (!a.d2s_r || strip_d2s) && a.stride == 1 && a.Cin == p.cinp && p.NTX > 1 &&
+                          (p.TW == 16 || p.TW == 32) && a.OW >= p.TW &&
+                          p.RS >= ppp && (npart == 1 || strip2 || strip_d2s) && ((a.Cout & 3) == 0 || strip_d2s) &&
                           a.y != a.skip && a.y != a.mask &&   // (the columns two strips share are computed twice: no in-place epilogue operand)
                           (long)a.H * a.W * a.Cin * 4 < (1L << 31) - 64 && (long)a.OH * a.OW * a.Cout * 4 < (1L << 31) - 64;
     if (g_use_pipe && p.cinp >= 16 && strip_ok) {

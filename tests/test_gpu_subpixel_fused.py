@@ -14,9 +14,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('shape,cin,r,k', [((32, 17, 17), 32, 3, 3), ((256, 41, 41), 32, 3, 3), ((3, 9, 13), 32, 4, 3),
                                            ((2, 7, 5), 32, 2, 3), ((2, 11, 6), 64, 3, 3), ((1, 20, 33), 3, 3, 5),
-                                           ((2, 6, 6), 32, 3, 1)],
-                         ids=['c2_f3', 'bandwidth_shape', 'r4', 'r2', 'cin64', 'rgb_5x5', '1x1'])
+                                           ((2, 6, 6), 32, 3, 1), ((1, 100, 203), 32, 3, 3), ((2, 37, 96), 32, 3, 3), ((1, 300, 260), 32, 3, 3),
+                                           ((3, 5, 61), 32, 3, 3), ((1, 70, 130), 32, 2, 3), ((1, 64, 128), 32, 4, 3)],
+                         ids=['c2_f3', 'bandwidth_shape', 'r4', 'r2', 'cin64', 'rgb_5x5', '1x1', 'wide_1x100x203', 'wide_2x37x96', 'wide_1x300x260',
+                              'wide_short_3x5x61', 'wide_r2', 'wide_r4'])
 def test_conv_with_subpixel_store_equals_conv_then_d2s(shape, cin, r, k):
+    """(The wide shapes: images too wide for full-width tiles.  Since round 4 the 32 -> 27 layer of r = 3 runs them on the
+    pipelined column-strip kernel with the sub-pixel map as a form of its deferred epilogue -- four 4-byte stores per lane,
+    channels 27..31 out of range; widths that are / are not multiples of the 32-column strip, tiles cut short by the image
+    and by the workgroup's range; r = 2 / 4 stay on the other kernels.)"""
     from ml_super_resolution_amd import ops
     n, h, w = shape
     g = torch.Generator(device='cuda').manual_seed(h * 100 + w)
@@ -31,6 +37,14 @@ def test_conv_with_subpixel_store_equals_conv_then_d2s(shape, cin, r, k):
     if n * h * w <= 40000:
         ref = O.depth_to_space(O.conv2d_fwd(x.cpu().numpy(), wt.cpu().numpy(), b.cpu().numpy(), 'SAME', None), r)
         close(ops.conv2d_fwd(x, wt, b, 'same', None, subpixel_r=r), ref)
+    # the same bits on conv path 0 (conv_mfma_kernel for every shape)
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0 = ops.conv2d_fwd(x, wt, b, 'same', None, subpixel_r=r)
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(ops.conv2d_fwd(x, wt, b, 'same', None, subpixel_r=r), y0)
     # VALID padding goes through the same store
     if k > 1 and h > k and w > k:
         two = ops.depth_to_space(ops.conv2d_fwd(x, wt, b, 'valid', None), r)
