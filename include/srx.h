@@ -191,12 +191,21 @@ int srx_stream_copy(const void* in, void* out, size_t bytes, srx_stream_t stream
  *   t1 = tanh(conv5x5(x; 3->64) + b1), t2 = tanh(conv3x3(t1; 64->32) + b2), y = conv3x3(t2; 32->3 r^2) + b3 (all SAME),
  *   hr[n, h r + dy, w r + dx, c] = y[n, h, w, (dy r + dx) 3 + c]
  * x [N,H,W,3], filters HWIO ([5,5,3,64], [3,3,64,32], [3,3,32,3 r^2]), hr [N,H r,W r,3], r in 2..4.  A workgroup chains
- * the three layers through LDS on a tile of <= 9x9 LR pixels (halo recomputed per tile): meant for latency-bound sizes
- * such as BASELINE configs[1] (batch 32 of 17x17 patches); for large images the per-layer launches do less work.
+ * the three layers through LDS on a tile of <= 16x16 LR pixels (halo recomputed per tile): meant for latency-bound sizes
+ * such as BASELINE configs[1] (batch 32 of 17x17 patches) and images of up to ~130 k pixels; beyond, the per-layer launches
+ * do less work.
  * Bit-identical to the three srx_conv2d_fwd launches (the last with subpixel_r). */
 int srx_espcn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                       const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
                       srx_stream_t stream);
+/* The same launch as the FORWARD PASS OF A TRAIN STEP (espcn/espcn/model_espcn.py:117-134 under the trainer of
+ * model_espcn.py:137-160): besides chaining the layers through LDS it writes what backward needs -- t1 [N,H,W,64] and
+ * t2 [N,H,W,32] (post-tanh; every pixel by the one tile that owns it) -- and y [N,H,W,3 r^2] in sub-pixel space (the loss of
+ * the reference is taken there), instead of the shuffled HR image.  Bit-identical to three srx_conv2d_fwd launches.
+ * t1 / t2 16-byte aligned. */
+int srx_espcn_forward_keep(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* t1, float* t2, float* y, int N, int H, int W, int r,
+                           srx_stream_t stream);
 
 /* SRCNN inference in ONE launch (srcnn/srcnn.py:100-130, tf.contrib.layers.convolution2d x 3, padding 'VALID'):
  *   t1 = relu(conv9x9(x; 3->64) + b1), t2 = relu(conv1x1(t1; 64->32) + b2), y = tanh(conv5x5(t2; 32->3) + b3)

@@ -7,7 +7,9 @@
 // MFMA's unused slots weighted zero.  Exact fp32.  The products of an output reach its accumulator in the same (kh, kw, ci)
 // order as in conv_mfma_kernel, cut into groups of four at other places -- and the results are BIT-IDENTICAL to that kernel's
 // on every shape tested (tests/test_gpu_ops.py: test_conv_rgb_input_packed_k_route_vs_oracle): v_mfma_f32_16x16x4_f32 adds its
-// four products to the accumulator one after the other in k order, and a zero-weighted slot adds +0.  Thresholds
+// four products to the accumulator one after the other in k order, and a zero-weighted slot adds +0 -- for FINITE inputs: the
+// slot past a filter row multiplies the next pixel's first channel by zero, so an Inf / NaN there (one column right of the
+// window) would reach this output too; images are finite (uint8-derived), conv path 0 has no such slot.  Thresholds
 // (srx_api.hip): 9x9 from 4,096 output pixels, 5x5 from 60,000 (smaller ESPCN inputs take the one-launch kernel).
 //
 // One workgroup of 8 waves per CU; a tile is 32 output rows x 64 output columns (its input halo: <= 40 x 72 pixels = 34.6 KB);
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
                 const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)cf < (unsigned)(a.W * 3));
                 lds[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (ih * a.W * 3 + cf) * 4 : kOobOffset, 0, 0));
             }
+            // the zero-weighted k slots of the tile's very last pixel lie past the staged floats: they must hold NUMBERS (0 x NaN
+            // is NaN; whatever an earlier kernel left in LDS is there otherwise -- found by scripts/fuzz_round4.py, round 4)
+#ifndef SRX_TEST_NO_PAD_ZERO
+            if (tid < 4) lds[rows * rowf + tid] = 0.0f;
+#endif
         }
         lds_barrier();
         float* yn = a.y + ((size_t)n * a.OH + h0) * a.OW * a.Cout;

@@ -27,6 +27,7 @@ namespace {
 struct EspcnArgs {
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     float* hr;
+    float *t1k, *t2k, *yk;       // KEEP (training forward): the activations t1 [N,H,W,64], t2 [N,H,W,32] and y [N,H,W,C3] in sub-pixel space
     int N, H, W, r, C3;          // C3 = 3 r^2
     int TY, TX;                  // tile (<= 16 x 16 LR output pixels)
     int tiles_y, tiles_x, units;
@@ -69,9 +70,10 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
     }
 
 // ---- f1: 5x5, 3 -> 64, tanh, on the tile grown by 2
-template <int G>
+template <int G, bool KEEP>
 __device__ __forceinline__ void espcn_f1_group(const EspcnArgs& a, const float* X0, float* T1, const float (&w1r)[25], f32x4 b1r,
-                                               int m0, int step, int n1, int w0, int w1, int oy, int ox, int wave, int li, int kq) {
+                                               int m0, int step, int n1, int w0, int w1, int oy, int ox, int wave, int li, int kq,
+                                               float* t1_img, int th, int tw) {
     int la[G];
     f32x4 acc[G];
 #pragma unroll
@@ -106,15 +108,20 @@ __device__ __forceinline__ void espcn_f1_group(const EspcnArgs& a, const float* 
             const int r = t / w1, c = t - r * w1;
             const bool in_img = (unsigned)(oy - 2 + r) < (unsigned)a.H && (unsigned)(ox - 2 + c) < (unsigned)a.W;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(T1 + t * kP1 + 16 * wave + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+            const f32x4 v = in_img ? tanh4(acc[i]) : z;
+            *reinterpret_cast<f32x4*>(T1 + t * kP1 + 16 * wave + 4 * kq) = v;
+            // KEEP: the tile's own pixels (not the halo other tiles compute as well) also go to global memory, once
+            if (KEEP && (unsigned)(r - 2) < (unsigned)th && (unsigned)(c - 2) < (unsigned)tw)
+                *reinterpret_cast<f32x4*>(t1_img + ((size_t)(oy - 2 + r) * a.W + (ox - 2 + c)) * 64 + 16 * wave + 4 * kq) = v;
         }
     }
 }
 
 // ---- f2: 3x3, 64 -> 32, tanh, on the tile grown by 1
-template <int G>
+template <int G, bool KEEP>
 __device__ __forceinline__ void espcn_f2_group(const EspcnArgs& a, const float* T1, float* T2, const float (&w2r)[144], f32x4 b2r,
-                                               int m0, int step, int n2, int w1, int w2, int oy, int ox, int ch2, int li, int kq) {
+                                               int m0, int step, int n2, int w1, int w2, int oy, int ox, int ch2, int li, int kq,
+                                               float* t2_img, int th, int tw) {
     int la[G];
     f32x4 acc[G];
 #pragma unroll
@@ -161,13 +168,16 @@ __device__ __forceinline__ void espcn_f2_group(const EspcnArgs& a, const float* 
             const int r = t / w2, c = t - r * w2;
             const bool in_img = (unsigned)(oy - 1 + r) < (unsigned)a.H && (unsigned)(ox - 1 + c) < (unsigned)a.W;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(T2 + t * kP2 + 16 * ch2 + 4 * kq) = in_img ? tanh4(acc[i]) : z;
+            const f32x4 v = in_img ? tanh4(acc[i]) : z;
+            *reinterpret_cast<f32x4*>(T2 + t * kP2 + 16 * ch2 + 4 * kq) = v;
+            if (KEEP && (unsigned)(r - 1) < (unsigned)th && (unsigned)(c - 1) < (unsigned)tw)
+                *reinterpret_cast<f32x4*>(t2_img + ((size_t)(oy - 1 + r) * a.W + (ox - 1 + c)) * 32 + 16 * ch2 + 4 * kq) = v;
         }
     }
 }
 
 // ---- f3: 3x3, 32 -> 3 r^2, stored through the sub-pixel map
-template <int G>
+template <int G, bool KEEP>
 __device__ __forceinline__ void espcn_f3_group(const EspcnArgs& a, const float* T2, float* hr_img, const float (&w3r)[72],
                                                const float (&b3r)[4], const int (&eo)[4], int m0, int step, int n3, int tw, int w2,
                                                int oy, int ox, int rc, int ch3, int li, int kq) {
@@ -213,15 +223,22 @@ __device__ __forceinline__ void espcn_f3_group(const EspcnArgs& a, const float* 
         const int t = 16 * (m0 + i * step) + li;
         if (t < n3) {
             const int r = t / tw, c = t - r * tw;
-            float* o = hr_img + ((size_t)(oy + r) * a.r * a.W + (ox + c)) * rc;
+            if (KEEP) {          // (training: y stays in sub-pixel space, [N,H,W,C3]; hr_img is y's image here)
+                float* o = hr_img + ((size_t)(oy + r) * a.W + (ox + c)) * a.C3 + 16 * ch3 + 4 * kq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (16 * ch3 + 4 * kq + e < a.C3) o[eo[e]] = acc[i][e];
+                for (int e = 0; e < 4; ++e)
+                    if (16 * ch3 + 4 * kq + e < a.C3) o[e] = acc[i][e];
+            } else {
+                float* o = hr_img + ((size_t)(oy + r) * a.r * a.W + (ox + c)) * rc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (16 * ch3 + 4 * kq + e < a.C3) o[eo[e]] = acc[i][e];
+            }
         }
     }
 }
 
-template <int NCH3>
+template <int NCH3, bool KEEP = false>
 __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* T1 = lds;
@@ -302,7 +319,8 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
 
         {   // f1: wave = channel chunk, all sub-tiles
             const int first = 0, step = 1, count = (n1 + 15) >> 4;
-#define SRX_F1(G) espcn_f1_group<G>(a, X0, T1, w1r, b1r, m_, step, n1, w0, w1, oy, ox, wave, li, kq);
+            float* t1_img = KEEP ? a.t1k + (size_t)n * a.H * a.W * 64 : nullptr;
+#define SRX_F1(G) espcn_f1_group<G, KEEP>(a, X0, T1, w1r, b1r, m_, step, n1, w0, w1, oy, ox, wave, li, kq, t1_img, th, tw);
             SRX_ESPCN_GROUPS(SRX_F1)
 #undef SRX_F1
         }
@@ -310,16 +328,17 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
         {   // f2: wave = (chunk, even / odd sub-tiles)
             const int nsub = (n2 + 15) >> 4;
             const int first = half2, step = 2, count = (nsub - half2 + 1) >> 1;
-#define SRX_F2(G) espcn_f2_group<G>(a, T1, T2, w2r, b2r, m_, step, n2, w1, w2, oy, ox, ch2, li, kq);
+            float* t2_img = KEEP ? a.t2k + (size_t)n * a.H * a.W * 32 : nullptr;
+#define SRX_F2(G) espcn_f2_group<G, KEEP>(a, T1, T2, w2r, b2r, m_, step, n2, w1, w2, oy, ox, ch2, li, kq, t2_img, th, tw);
             SRX_ESPCN_GROUPS(SRX_F2)
 #undef SRX_F2
         }
         __syncthreads();
         if (on3) {   // f3: wave = (chunk, every W3-th sub-tile)
-            float* hr_img = a.hr + (size_t)n * a.H * a.r * hr_row;
+            float* hr_img = KEEP ? a.yk + (size_t)n * a.H * a.W * a.C3 : a.hr + (size_t)n * a.H * a.r * hr_row;
             const int nsub = (n3 + 15) >> 4;
             const int first = part3, step = W3, count = (nsub - part3 + W3 - 1) / W3;
-#define SRX_F3(G) espcn_f3_group<G>(a, T2, hr_img, w3r, b3r, eo, m_, step, n3, tw, w2, oy, ox, rc, ch3, li, kq);
+#define SRX_F3(G) espcn_f3_group<G, KEEP>(a, T2, hr_img, w3r, b3r, eo, m_, step, n3, tw, w2, oy, ox, rc, ch3, li, kq);
             SRX_ESPCN_GROUPS(SRX_F3)
 #undef SRX_F3
         }
@@ -331,16 +350,20 @@ __global__ __launch_bounds__(256, 1) void espcn_fused_kernel(const EspcnArgs a) 
 
 using namespace srx;
 
-extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                                 const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
-                                 srx_stream_t stream) {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !hr) return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
+static int espcn_launch(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, float* hr, float* t1k, float* t2k, float* yk, int N, int H, int W, int r,
+                        srx_stream_t stream) {
+    const bool keep = yk != nullptr;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || (!keep && !hr) || (keep && (!t1k || !t2k)))
+        return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
+    if (keep && (((uintptr_t)t1k | (uintptr_t)t2k) & 15u)) return set_error(SRX_ERR_ALIGN, "t1 / t2 must be 16-byte aligned");
     if (N <= 0 || H <= 0 || W <= 0) return set_error(SRX_ERR_BAD_ARG, "non-positive dimension");
     if (r < 2 || r > 4) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: scaling factor %d (2..4 are built)", r);
     if (((uintptr_t)b1 | (uintptr_t)b2) & 15u) return set_error(SRX_ERR_ALIGN, "bias pointers must be 16-byte aligned");
     if ((long)N * H * W * 3L * r * r >= (1L << 31)) return set_error(SRX_ERR_UNSUPPORTED, "espcn_forward: output beyond 32-bit offsets");
     EspcnArgs a;
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.hr = hr;
+    a.t1k = t1k; a.t2k = t2k; a.yk = yk;
     a.N = N; a.H = H; a.W = W; a.r = r; a.C3 = 3 * r * r;
     // Tile shape: <= 16 x 16; among all shapes the one with the least MFMA time: rounds of workgroups over the CUs x the
     // work of one tile (every phase costs a tile its sub-tiles of 16 pixels: 25 / 144 / 72 MFMAs each, shared by 4 / 2 / W3
@@ -370,9 +393,28 @@ extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b
     const int grid = (int)(units < (long)cus ? units : (long)cus);
     const size_t lds = (size_t)(kT1 + kShared) * 4;
     hipError_t e;
-    if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1>, a, grid, lds, (hipStream_t)stream);
-    else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2>, a, grid, lds, (hipStream_t)stream);
-    else e = launch_with_lds(espcn_fused_kernel<3>, a, grid, lds, (hipStream_t)stream);
+    if (keep) {
+        if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1, true>, a, grid, lds, (hipStream_t)stream);
+        else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2, true>, a, grid, lds, (hipStream_t)stream);
+        else e = launch_with_lds(espcn_fused_kernel<3, true>, a, grid, lds, (hipStream_t)stream);
+    } else {
+        if (nch3 == 1) e = launch_with_lds(espcn_fused_kernel<1>, a, grid, lds, (hipStream_t)stream);
+        else if (nch3 == 2) e = launch_with_lds(espcn_fused_kernel<2>, a, grid, lds, (hipStream_t)stream);
+        else e = launch_with_lds(espcn_fused_kernel<3>, a, grid, lds, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return set_error(SRX_ERR_LAUNCH, "espcn_forward launch failed: %s", hipGetErrorString(e));
     return SRX_OK;
+}
+
+extern "C" int srx_espcn_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 const float* w3, const float* b3, float* hr, int N, int H, int W, int r,
+                                 srx_stream_t stream) {
+    return espcn_launch(x, w1, b1, w2, b2, w3, b3, hr, nullptr, nullptr, nullptr, N, H, W, r, stream);
+}
+
+extern "C" int srx_espcn_forward_keep(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      const float* w3, const float* b3, float* t1, float* t2, float* y, int N, int H, int W, int r,
+                                      srx_stream_t stream) {
+    if (!y) return set_error(SRX_ERR_BAD_ARG, "null tensor pointer");
+    return espcn_launch(x, w1, b1, w2, b2, w3, b3, nullptr, t1, t2, y, N, H, W, r, stream);
 }

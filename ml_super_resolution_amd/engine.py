@@ -75,6 +75,7 @@ class ConvStack(object):
         self.global_step = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._acts = None
+        self.forward_keep_hook = None      # optional: fn(x, [per-layer output buffers]) -> True when it ran the whole forward pass
         self._bufs = {}
         self._ws = None
         self.grad_hook = None      # called with the flat gradient after backward (DP all-reduce)
@@ -154,6 +155,12 @@ class ConvStack(object):
         """Returns the stack output; with keep=True every layer's output is kept for backward()
         and exposed through `self.acts` (acts[0] is the input, acts[i+1] layer i's output)."""
         shapes = self._shapes(x.shape)
+        if keep and self.forward_keep_hook is not None:
+            # a model's one-launch forward pass (ESPCN: srx_espcn_forward_keep) writing the same activation buffers
+            outs = [self._buf(('act', i), shapes[i]) for i in range(len(self.specs))]
+            if self.forward_keep_hook(x, outs):
+                self._acts = self.acts = [x] + outs
+                return outs[-1]
         acts = [x]
         t = x
         last = len(self.specs) - 1

@@ -53,6 +53,22 @@ class EspcnModel(object):
                                "f3's epilogue, 3 launches%s" % (self.single_launch_max_pixels,
                                                                ' replayed as one HIP graph' if self.use_graph else ', eager'))
 
+        # the forward pass of a TRAIN step in one launch too (srx_espcn_forward_keep: writes t1, t2 and y for backward);
+        # SRX_ESPCN_FUSED_TRAIN=0: three launches (A/B).  Measured (scripts/time_espcn_train.py, whole train step, one launch
+        # against three): batch 16 / 32 / 64 of 17 x 17: 119 / 128 / 154 us against 149 / 144 / 169; batch 128 (37 k pixels): level.
+        self.use_single_launch_train = os.environ.get('SRX_ESPCN_FUSED_TRAIN', '1') != '0'
+        self.single_launch_train_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_TRAIN_MAX_PIXELS', '30000'))
+        self.stack.forward_keep_hook = self._forward_keep_one_launch
+
+    def _forward_keep_one_launch(self, x, outs):
+        n, h, w, _ = x.shape
+        if not (self.use_single_launch and self.use_single_launch_train and x.is_cuda and n * h * w <= self.single_launch_train_max_pixels
+                and 2 <= self.scaling_factor <= 4):
+            return False
+        st = self.stack
+        ops.espcn_forward_keep(x.contiguous(), [(st.kernel(i), st.bias(i)) for i in range(3)], self.scaling_factor, outs[0], outs[1], outs[2])
+        return True
+
     # ---- eager API -----------------------------------------------------------------------------
     def forward(self, lr_source, keep=False):
         """sr_result in sub-pixel space [N,H,W,3*r*r]."""

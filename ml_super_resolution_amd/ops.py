@@ -179,6 +179,25 @@ def espcn_forward(x, params, r, out=None):
     return out
 
 
+def espcn_forward_keep(x, params, r, t1, t2, y):
+    """ESPCN's forward pass of a train step in one launch -- srx_espcn_forward_keep: writes the activations t1 [N,H,W,64],
+    t2 [N,H,W,32] and the output y [N,H,W,3 r^2] (sub-pixel space) into the given tensors.  Returns y."""
+    _chk(x, 'x')
+    for k, b in params:
+        _chk(k, 'kernel'); _chk(b, 'bias')
+    (w1, b1), (w2, b2), (w3, b3) = params
+    N, H, W, C = x.shape
+    if C != 3 or tuple(w1.shape) != (5, 5, 3, 64) or tuple(w2.shape) != (3, 3, 64, 32) or tuple(w3.shape) != (3, 3, 32, 3 * r * r):
+        raise ValueError('espcn_forward_keep: shapes do not describe ESPCN 5-3-3 with scaling factor %d' % r)
+    for t, c, name in ((t1, 64, 't1'), (t2, 32, 't2'), (y, 3 * r * r, 'y')):
+        _chk(t, name)
+        if tuple(t.shape) != (N, H, W, c):
+            raise ValueError('espcn_forward_keep: %s has shape %s, expected %s' % (name, tuple(t.shape), (N, H, W, c)))
+    check(lib().srx_espcn_forward_keep(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(t1), _ptr(t2),
+                                       _ptr(y), N, H, W, int(r), _stream()), 'srx_espcn_forward_keep')
+    return y
+
+
 def srcnn_forward(x, params, out=None):
     """SRCNN 9-1-5 VALID inference in one launch -- srx_srcnn_forward.  params = [(w1, b1), (w2, b2), (w3, b3)] (HWIO kernels);
     x [N,H,W,3] -> [N,H-12,W-12,3]."""

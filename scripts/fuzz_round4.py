@@ -4,7 +4,9 @@ tests/): the exact-rows strip filter gradient (wgrad_rows_strip_kernel: any widt
 width, VALID and SAME, ranges that cut strips and images), the (kw, co)-rows 5x5 32 -> 3 kernel (conv_kwrows_kernel), the
 sub-pixel map on shapes whose chunks end within 6 float4 of a multiple of 256 (the LDS slot guard of round 4), and the
 device-state Adam against the host-argument one.
-Usage: fuzz_round4.py [cases] [seed] [wgrad_strip|kwrows|subpixel|adam]"""
+Late in the round: the RGB-input packed-K kernel (oracle + bit-identity with conv path 0), the two-chunk pipelined strips (tanh epilogue;
+sub-pixel epilogue), the one-launch ESPCN kernel with tiles up to 16 x 16, the exact-rows filter gradient on 41-pixel rows.
+Usage: fuzz_round4.py [cases] [seed] [wgrad_strip|kwrows|subpixel|adam|pack3|strip2|espcn_one_launch|wgrad_rows41]"""
 import os, sys
 import numpy as np
 import torch
@@ -46,8 +48,10 @@ def case_kwrows(rng):
     act = [None, 'relu', 'tanh', 'sigmoid'][rng.integers(4)]
     n = int(rng.integers(1, 4))
     h, w = int(rng.integers(60, 400)), int(rng.integers(60, 400))
-    while n * (h - 4) * (w - 4) < 60000:
-        h += 37; w += 41
+    if rng.random() < 0.5:                      # (the route starts at 4,096 output pixels since late round 4: small shapes too)
+        h, w = int(rng.integers(9, 120)), int(rng.integers(9, 120))
+    while n * (h - 4) * (w - 4) < 4096:
+        h += 17; w += 11
     x = rng.uniform(-1, 1, (n, h, w, 32)).astype(np.float32)
     wt = (rng.normal(size=(5, 5, 32, 3)) / np.sqrt(800)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, 3).astype(np.float32)
@@ -94,10 +98,106 @@ def case_adam(rng):
     return ok, 'adam n=%d t0=%d betas %g %g' % (n, t0, b1, b2)
 
 
+def _path0(fn):
+    from ml_super_resolution_amd import _lib
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        return fn()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+
+
+def case_pack3(rng):
+    # RGB-input 9x9 (from 4,096 output pixels) / 5x5 (from 60,000): oracle parity and BIT-identity with conv path 0
+    k = 9 if rng.random() < 0.6 else 5
+    pad = 'VALID' if rng.random() < 0.5 else 'SAME'
+    act = [None, 'relu', 'tanh'][rng.integers(3)]
+    n = int(rng.integers(1, 5))
+    h, w = int(rng.integers(k + 1, 200)), int(rng.integers(k + 1, 200))
+    need = 4096 if k == 9 else 60000
+    while n * (h - k + 1) * (w - k + 1) < need:
+        h += 23; w += 29
+    x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32)
+    wt = (rng.normal(size=(k, k, 3, 64)) / np.sqrt(k * k * 3)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, 64).astype(np.float32)
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    y = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    y0 = _path0(lambda: ops.conv2d_fwd(xd, wd, bd, pad, act))
+    ok_ref, ok_eq = close(y, O.c_conv2d_fwd(x, wt, b, pad, act)), torch.equal(y, y0)
+    return ok_ref and ok_eq, 'pack3 k%d %s %s %dx%dx%d (oracle %s, path 0 equal %s, max diff %g)' % (k, pad, act, n, h, w, ok_ref, ok_eq,
+                                                                                                 (y - y0).abs().max().item())
+
+
+def case_strip2(rng):
+    # 3x3 64 -> 32 (none / relu / tanh) and 3x3 32 -> 27 through the sub-pixel map on images too wide for full-width tiles
+    d2s = rng.random() < 0.5
+    n = int(rng.integers(1, 4))
+    h = int(rng.integers(1, 60)) if rng.random() < 0.7 else int(rng.integers(60, 300))
+    w = int(rng.integers(59, 400))
+    if n * h * w > 90000:
+        n = 1; h = max(1, 90000 // w)
+    if d2s:
+        x = rng.uniform(-1, 1, (n, h, w, 32)).astype(np.float32)
+        wt = (rng.normal(size=(3, 3, 32, 27)) / np.sqrt(288)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, 27).astype(np.float32)
+        xd, wd, bd = dev(x), dev(wt), dev(b)
+        y = ops.conv2d_fwd(xd, wd, bd, 'same', None, subpixel_r=3)
+        y0 = _path0(lambda: ops.conv2d_fwd(xd, wd, bd, 'same', None, subpixel_r=3))
+        ref = O.depth_to_space(O.c_conv2d_fwd(x, wt, b, 'SAME', None), 3)
+        return close(y, ref) and torch.equal(y, y0), 'strip d2s %dx%dx%d' % (n, h, w)
+    act = [None, 'relu', 'tanh'][rng.integers(3)]
+    x = rng.uniform(-1, 1, (n, h, w, 64)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, 64, 32)) / np.sqrt(576)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, 32).astype(np.float32)
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    y = ops.conv2d_fwd(xd, wd, bd, 'same', act)
+    y0 = _path0(lambda: ops.conv2d_fwd(xd, wd, bd, 'same', act))
+    return close(y, O.c_conv2d_fwd(x, wt, b, 'SAME', act)) and torch.equal(y, y0), 'strip2 %s %dx%dx%d' % (act, n, h, w)
+
+
+def case_espcn_one_launch(rng):
+    # srx_espcn_forward on shapes that take tiles of every size up to 16 x 16, against the per-layer launches of conv path 0
+    r = int(rng.integers(2, 5))
+    n = int(rng.integers(1, 4)) if rng.random() < 0.7 else int(rng.integers(4, 300))
+    h, w = int(rng.integers(1, 260)), int(rng.integers(1, 260))
+    if n * h * w > 70000:
+        n = 1
+    if n * h * w > 70000:
+        h = max(1, 70000 // w)
+    x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32)
+    ws = [(rng.normal(size=(5, 5, 3, 64)) * 0.1).astype(np.float32), (rng.normal(size=(3, 3, 64, 32)) * 0.05).astype(np.float32),
+          (rng.normal(size=(3, 3, 32, 3 * r * r)) * 0.06).astype(np.float32)]
+    bs = [rng.uniform(-0.1, 0.1, c).astype(np.float32) for c in (64, 32, 3 * r * r)]
+    xd = dev(x)
+    params = [(dev(a), dev(b)) for a, b in zip(ws, bs)]
+    one = ops.espcn_forward(xd, params, r)
+
+    def three():
+        t = ops.conv2d_fwd(xd, params[0][0], params[0][1], 'same', 'tanh')
+        t = ops.conv2d_fwd(t, params[1][0], params[1][1], 'same', 'tanh')
+        return ops.conv2d_fwd(t, params[2][0], params[2][1], 'same', None, subpixel_r=r)
+    y0 = _path0(three)
+    ok = torch.equal(one, y0)
+    if n * h * w <= 20000:
+        ok = ok and close(one, O.depth_to_space(O.espcn_forward(x, list(zip(ws, bs))), r))
+    return ok, 'espcn one launch r%d %dx%dx%d' % (r, n, h, w)
+
+
+def case_wgrad_rows41(rng):
+    n = int(rng.integers(1, 40))
+    h = 41 if rng.random() < 0.5 else int(rng.integers(1, 90))
+    x = rng.uniform(-1, 1, (n, h, 41, 64)).astype(np.float32)
+    dpre = rng.normal(size=(n, h, 41, 64)).astype(np.float32)
+    dw, db = ops.conv2d_bwd_filter(dev(x), dev(dpre), (3, 3, 64, 64), 'SAME')
+    dw_ref, db_ref = O.c_conv2d_bwd_filter(x, dpre, (3, 3), 'SAME')
+    dw2, db2 = ops.conv2d_bwd_filter(dev(x), dev(dpre), (3, 3, 64, 64), 'SAME')
+    return close(dw, dw_ref) and close(db, db_ref) and torch.equal(dw, dw2) and torch.equal(db, db2), 'wgrad rows41 %dx%d' % (n, h)
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    kinds = [case_wgrad_strip, case_kwrows, case_subpixel, case_adam]
+    kinds = [case_wgrad_strip, case_kwrows, case_subpixel, case_adam, case_pack3, case_strip2, case_espcn_one_launch, case_wgrad_rows41]
     if len(sys.argv) > 3:
         kinds = [k for k in kinds if k.__name__ == 'case_' + sys.argv[3]]
     nbad = 0

@@ -89,6 +89,38 @@ def test_espcn_train_step_vs_oracle():
     close(st.kernel(0), O.adam_tf(k1, dk1, 0.0, 0.0, 0.01, 1)[0], 1e-4)
 
 
+@pytest.mark.parametrize('n,h,w,r', [(64, 17, 17, 3), (5, 23, 40, 2), (3, 9, 9, 4), (70, 17, 17, 3)],
+                         ids=['recipe_batch', 'r2_ragged', 'r4', 'more_tiles_than_cus'])
+def test_espcn_train_forward_in_one_launch_equals_three_launches(n, h, w, r):
+    """The forward pass of ESPCN's train step as ONE launch (srx_espcn_forward_keep: the layers chained through LDS, t1 / t2 / y
+    written for backward; espcn/espcn/model_espcn.py:117-160) against the three per-layer launches: activations, loss,
+    gradients and the weights after three Adam steps bit-identical; t1 against the oracle."""
+    from ml_super_resolution_amd.espcn import model_espcn
+    g = torch.Generator(device='cuda').manual_seed(n * 100 + h)
+    x = torch.rand((n, h, w, 3), device='cuda', generator=g) * 2 - 1
+    target = torch.rand((n, h, w, 3 * r * r), device='cuda', generator=g) * 2 - 1
+    res = []
+    for fused in (True, False):
+        m = model_espcn.EspcnModel(r, device='cuda', seed=77)
+        for i in range(3):
+            m.stack.bias(i).copy_(torch.linspace(-0.1, 0.1, m.stack.bias(i).numel(), device='cuda'))
+        m.use_single_launch_train = fused
+        m.single_launch_train_max_pixels = 10 ** 9
+        m.stack.use_step_graph = False
+        y = m.stack.forward(x, keep=True)
+        acts = [a.clone() for a in m.stack.acts]
+        losses = [float(m.train_step(x, target, 1e-3)) for _ in range(3)]
+        res.append((y.clone(), acts, losses, m.stack.grads.clone(), m.stack.params.clone()))
+    (y1, a1, l1, g1, p1), (y0, a0, l0, g0, p0) = res
+    assert torch.equal(y1, y0) and all(torch.equal(u, v) for u, v in zip(a1, a0))
+    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(p1, p0)
+    if n * h * w <= 6000:
+        m = model_espcn.EspcnModel(r, device='cuda', seed=77)
+        k1 = m.stack.kernel(0).cpu().numpy()
+        b1 = np.linspace(-0.1, 0.1, 64).astype(np.float32)
+        close(a1[1], O.conv2d_fwd(x.cpu().numpy(), k1, b1, 'SAME', 'tanh'))
+
+
 def test_srcnn_forward_and_train_vs_oracle(golden_nets):
     from ml_super_resolution_amd import graph
     from ml_super_resolution_amd.srcnn import srcnn

@@ -669,6 +669,13 @@ def test_conv_rgb_input_packed_k_route_vs_oracle(shape, ops):
         _lib.lib().srx_set_conv_path(old)
     close(y0, ref)
     assert torch.equal(y, y0), float((y - y0).abs().max())
+    # Regression (found by scripts/fuzz_round4.py): the zero-weighted k slots of a tile's last pixel read one float past the
+    # staged tile; whatever an earlier kernel left there must not matter.  Poison every CU's LDS with NaNs (a 3x3 64 -> 64 layer
+    # on a NaN image stages them into both 75-KB tile buffers), then run the layer again.
+    nan_img = torch.full((256, 41, 41, 64), float('nan'), device='cuda')
+    ops.conv2d_fwd(nan_img, torch.zeros((3, 3, 64, 64), device='cuda'), torch.zeros(64, device='cuda'), 'same', 'relu')
+    y2 = ops.conv2d_fwd(xd, wd, bd, pad, act)
+    assert torch.isfinite(y2).all() and torch.equal(y2, y)
 
 
 @pytest.mark.parametrize('shape', [(2, 11, 13, 7, 7, 8, 5, 'SAME'), (1, 9, 9, 4, 4, 3, 16, 'SAME'), (2, 10, 12, 2, 2, 64, 64, 'VALID'), (1, 20, 20, 7, 7, 32, 48, 'VALID'),
