@@ -330,6 +330,11 @@ int srx_upsample_nearest(const float* in, float* out, int N, int H, int W, int C
 int srx_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f,
                              srx_stream_t stream);
 
+/* Test aid: fills the LDS of every CU with quiet NaNs (one launch).  A kernel that reads LDS it has not written must not
+ * depend on what it finds there; the Python wrappers call this before every entry point when SRX_POISON_LDS=1, which turns such a
+ * dependence into NaNs in the parity tests (round 4: conv_pack3_kernel read one float behind its tile).  No reference counterpart. */
+int srx_debug_poison_lds(srx_stream_t stream);
+
 /* Gradient through t = relu(x + f(x)) of a residual block (enet/enet/model_enet.py:8-31) where the
  * gradients via the skip path and via the conv path arrive separately:
  * out = (y > 0) ? a + b : 0, y = the block input as saved (post-ReLU).  out may alias a or b. */

@@ -26,7 +26,7 @@ EXPORTS = [
     'srx_adam_tf_step', 'srx_adam_tf_step_dev', 'srx_momentum_clip_step', 'srx_rownorm_loss_fwd_bwd', 'srx_psnr', 'srx_ssim', 'srx_ssim_scratch_bytes', 'srx_saturate_u8', 'srx_affine', 'srx_u8_to_unit_float', 'srx_gaussian_blur', 'srx_resize_bilinear',
     'srx_upsample_nearest', 'srx_upsample_nearest_bwd', 'srx_add_relu_grad',
     'srx_conv2d_bwd_data_acc', 'srx_conv3x3_blocked', 'srx_conv3x3_blocked_bwd_filter_workspace_bytes', 'srx_conv3x3_blocked_bwd_filter',
-    'srx_espcn_forward', 'srx_espcn_forward_keep', 'srx_srcnn_forward', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_maxpool2x2_bwd_masked', 'srx_subsample2', 'srx_subsample2_bwd',
+    'srx_espcn_forward', 'srx_espcn_forward_keep', 'srx_debug_poison_lds', 'srx_srcnn_forward', 'srx_maxpool2x2', 'srx_maxpool2x2_bwd', 'srx_maxpool2x2_bwd_masked', 'srx_subsample2', 'srx_subsample2_bwd',
     'srx_channel_blocks_to_nhwc', 'srx_nhwc_to_channel_blocks', 'srx_channel_normalize', 'srx_channel_normalize_bwd',
     'srx_extract_patches16', 'srx_texture_gram', 'srx_texture_gram_bwd', 'srx_pil_resample_ksize', 'srx_pil_resample_coeffs', 'srx_resample_u8', 'srx_u8_to_pm1', 'srx_log_loss', 'srx_vgg_preprocess', 'srx_add_scaled', 'srx_resize_bicubic_tf', 'srx_column_sums', 'srx_gemm_workspace_bytes', 'srx_gemm',
 ]
@@ -106,6 +106,7 @@ def lib():
     L.srx_conv2d_bwd_data_acc.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
     L.srx_espcn_forward.argtypes = [vp] * 8 + [i, i, i, i, vp]
     L.srx_espcn_forward_keep.argtypes = [vp] * 10 + [i, i, i, i, vp]
+    L.srx_debug_poison_lds.argtypes = [vp]
     L.srx_srcnn_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp]
     L.srx_conv3x3_blocked.argtypes = [vp, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
     L.srx_conv3x3_blocked_bwd_filter_workspace_bytes.restype = sz

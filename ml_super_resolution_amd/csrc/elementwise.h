@@ -39,4 +39,5 @@ hipError_t launch_psnr(const float* a, const float* b, float* out, int N, size_t
 hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int C, int f, hipStream_t s);
 hipError_t launch_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W, int C, int f, hipStream_t s);
 hipError_t launch_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t n, hipStream_t s);
+hipError_t launch_poison_lds(hipStream_t s);
 }  // namespace srx

@@ -1317,4 +1317,27 @@ hipError_t launch_add_relu_grad(const float* a, const float* b, const float* y, 
     return hipGetLastError();
 }
 
+// Test aid (srx_debug_poison_lds): fills the whole LDS of every CU with quiet NaNs.  A kernel that reads LDS it has not written
+// -- a pad slot, a zero-weighted operand -- gives the same answer whatever ran before it only if it does not depend on those
+// bytes; with the LDS poisoned before every call a dependence shows up as a NaN in the parity tests.
+__global__ __launch_bounds__(256) void poison_lds_kernel(int n4) {
+    extern __shared__ __attribute__((aligned(16))) float lds_poison[];
+    const f32x4 q = {__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
+    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<f32x4*>(lds_poison)[i] = q;
+    __syncthreads();
+    // (read one value back into a side effect nobody sees, so that the stores are not dropped)
+    if (lds_poison[(threadIdx.x * 61) % (4 * n4)] == 0.0f) __builtin_amdgcn_s_sleep(1);
+}
+hipError_t launch_poison_lds(hipStream_t s) {
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    // one workgroup fills a CU's whole LDS, so no two share a CU; four rounds' worth of them reach every CU
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024, s, 160 * 1024 / 16);
+    return hipGetLastError();
+}
+
 }  // namespace srx

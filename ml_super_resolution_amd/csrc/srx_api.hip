@@ -949,6 +949,12 @@ int srx_upsample_nearest_bwd(const float* dout, float* din, int N, int H, int W,
     SRX_CHECK_LAUNCH(launch_upsample_nearest_bwd(dout, din, N, H, W, C, f, (hipStream_t)stream), "upsample_bwd");
 }
 
+int srx_debug_poison_lds(srx_stream_t stream) {
+    hipError_t err = launch_poison_lds((hipStream_t)stream);
+    if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "poison_lds launch failed: %s", hipGetErrorString(err));
+    return SRX_OK;
+}
+
 int srx_add_relu_grad(const float* a, const float* b, const float* y, float* out, size_t numel, srx_stream_t stream) {
     if (!a || !b || !y || !out) return fail(SRX_ERR_BAD_ARG, "null pointer");
     if (numel == 0) return SRX_OK;

@@ -1,11 +1,25 @@
 """Thin op wrappers over the C ABI.  Tensors are torch CUDA(ROCm) float32, NHWC activations,
 HWIO filters.  Every call is asynchronous on torch's current stream."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib
-from ._lib import ACT_BY_NAME, PAD_BY_NAME, ConvDesc, check, lib
+from ._lib import ACT_BY_NAME, PAD_BY_NAME, ConvDesc, check
+from ._lib import lib as _load_lib
+
+# SRX_POISON_LDS=1 (test aid): every CU's LDS is filled with NaNs before each call into the library, so a kernel that depends on
+# LDS bytes it has not written shows up in the parity tests (include/srx.h: srx_debug_poison_lds)
+_POISON_LDS = os.environ.get('SRX_POISON_LDS', '0') == '1'
+
+
+def lib():
+    L = _load_lib()
+    if _POISON_LDS and torch.cuda.is_available():
+        L.srx_debug_poison_lds(_stream())
+    return L
+
 
 
 def _stream():

@@ -749,3 +749,20 @@ def test_conv_3x3_64_to_32_on_column_strips_of_the_pipelined_kernel(shape, ops):
     finally:
         _lib.lib().srx_set_conv_path(old)
     assert torch.equal(y, y0)
+
+
+def test_debug_poison_lds_entry_point(ops):
+    """srx_debug_poison_lds (test aid: NaNs into every CU's LDS; SRX_POISON_LDS=1 makes the wrappers call it before every
+    entry point -- the whole -m gpu suite is green that way, profiles/r04_ab_suite.txt) launches, and a layer run right after
+    it does not see the NaNs."""
+    from ml_super_resolution_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, 41, 41, 64)).astype(np.float32)
+    w = rng.normal(0, 0.04, (3, 3, 64, 64)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (64,)).astype(np.float32)
+    ref = O.c_conv2d_fwd(x, w, b, 'SAME', 'relu')
+    for _ in range(2):
+        assert _lib.lib().srx_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        y = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', 'relu')
+        close(y, ref)

@@ -49,6 +49,7 @@ hipError_t launch_psnr(const float*, const float*, float*, int, size_t, float, h
 hipError_t launch_upsample_nearest(const float*, float*, int, int, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_upsample_nearest_bwd(const float*, float*, int, int, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_add_relu_grad(const float*, const float*, const float*, float*, size_t, hipStream_t) { return hipSuccess; }
+hipError_t launch_poison_lds(hipStream_t) { return hipSuccess; }
 }  // namespace srx
 
 static std::atomic<int> failures{0};
