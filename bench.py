@@ -405,6 +405,8 @@ def extras(model, dev, stream, x64, y64, px):
         eb = 64
         elr = torch.rand((eb, 17, 17, 3), device=dev) * 2 - 1
         ehr = torch.rand((eb, 17, 17, 27), device=dev) * 2 - 1
+        default_replays = e3.stack.step_graph_max_pixels is None or eb * 17 * 17 <= e3.stack.step_graph_max_pixels
+        e3.stack.step_graph_max_pixels = None              # (measure the replay whatever size the model stops replaying at)
         for _ in range(6):
             e3.train_step(elr, ehr, 1e-3)
         st_in = e3.stack.static_step_inputs(elr.shape, ehr.shape)     # batches written straight into the captured step's inputs
@@ -423,6 +425,7 @@ def extras(model, dev, stream, x64, y64, px):
         best = min(us_g, us_e)
         out['espcn_train_us'] = {'batch': eb, 'patch': '17x17 LR, r = 3', 'graph_replay_us': round(us_g, 2), 'eager_launches_us': round(us_e, 2),
                                  'eager_three_launch_forward_us': round(us_3, 2),
+                                 'default_route': 'graph replay' if default_replays else 'eager launches (the model replays batches of up to %s LR pixels)' % os.environ.get('SRX_ESPCN_STEP_GRAPH_MAX_PIXELS', '12000'),
                                  'speedup': round(us_e / us_g, 3), 'patches_per_s': round(eb / (best * 1e-6), 0),
                                  'what': 'ESPCN train step (forward in ONE launch that keeps t1 / t2 / y for backward -- srx_espcn_forward_keep --, MSE, '
                                          '3 wgrad + reduce, 2 dgrad, TF-Adam with device-resident step count) as ONE replayed HIP graph vs the same launches '

@@ -75,6 +75,7 @@ class ConvStack(object):
         self.global_step = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._acts = None
+        self.step_graph_max_pixels = None  # optional: input pixels (N*H*W) above which train_step_replay issues eager launches
         self.forward_keep_hook = None      # optional: fn(x, [per-layer output buffers]) -> True when it ran the whole forward pass
         self._bufs = {}
         self._ws = None
@@ -349,6 +350,8 @@ class ConvStack(object):
             return self.loss
         if not self.use_step_graph or self.grad_hook is not None or self.device.type != 'cuda' or self.overlap_reduce:
             return eager(x, target)
+        if self.step_graph_max_pixels is not None and x.shape[0] * x.shape[1] * x.shape[2] > self.step_graph_max_pixels:
+            return eager(x, target)          # (measured per model: beyond this size the replay is no faster than the launches)
         opt_key = (float(beta1), float(beta2), float(eps)) if momentum is None else ('momentum', float(lr), float(momentum), float(gradient_cap))
         key = (tuple(x.shape), tuple(target.shape)) + opt_key
         ent = self._step_graphs.get(key)

@@ -59,6 +59,10 @@ class EspcnModel(object):
         self.use_single_launch_train = os.environ.get('SRX_ESPCN_FUSED_TRAIN', '1') != '0'
         self.single_launch_train_max_pixels = int(os.environ.get('SRX_ESPCN_FUSED_TRAIN_MAX_PIXELS', '30000'))
         self.stack.forward_keep_hook = self._forward_keep_one_launch
+        # train steps are replayed as a HIP graph for small batches only: measured (bench.py espcn_train_us, scripts/time_espcn_train.py)
+        # batch 16 / 32 of 17 x 17: replay 119 / 128 us against 155 / 164 us of eager launches; batch 64: 155 against 148 -- the
+        # launches of the larger problem keep the queue fed by themselves
+        self.stack.step_graph_max_pixels = int(os.environ.get('SRX_ESPCN_STEP_GRAPH_MAX_PIXELS', '12000'))
 
     def _forward_keep_one_launch(self, x, outs):
         n, h, w, _ = x.shape

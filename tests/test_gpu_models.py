@@ -490,6 +490,7 @@ def test_train_step_graph_replay_equals_eager_launches(net):
     assert torch.equal(ma.stack.params, mb.stack.params)
     ma.stack.use_step_graph = False
     mb.stack.use_step_graph = True           # (whatever SRX_STEP_GRAPH says)
+    mb.stack.step_graph_max_pixels = None    # (and whatever size the model stops replaying at)
     losses = []
     for i in range(14):
         lr = 1e-3 if i < 6 else 3e-4
