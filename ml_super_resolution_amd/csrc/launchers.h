@@ -19,6 +19,7 @@ bool launch_pipe_k3c64(const ConvKey& k, const ConvArgs& a, int grid, size_t lds
 bool launch_pipe_other(const ConvKey& k, const ConvArgs& a, int grid, size_t lds, hipStream_t s, hipError_t* err);
 bool launch_wgrad_narrow(const ConvKey& k, const WgradArgs& a, int grid, hipStream_t s, hipError_t* err);
 bool launch_conv_narrow(const ConvKey& k, const ConvArgs& a, hipStream_t s, hipError_t* err);
+bool launch_conv_1x1(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err);
 bool launch_conv_rows3x3(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err);
 bool launch_conv_pack3(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err);
 bool launch_conv_kwrows(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err);

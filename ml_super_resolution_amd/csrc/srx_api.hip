@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels, strip_d2s;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels, strip_d2s, conv_1x1_min_pixels;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -47,6 +47,8 @@ Knobs read_knobs() {
     // gradient on wgrad_kwcols_kernel: from this many output pixels (below: the one-launch ESPCN kernel's window and the
     // training patches, measured on the older kernels only)
     k.big_route_min_pixels = env_int("SRX_BIG_ROUTE_MIN_PIXELS", 60000);
+    // 1x1 forward / data gradient (32 / 64 channels) on the streaming conv_1x1_kernel from this many pixels (negative: never)
+    k.conv_1x1_min_pixels = env_int("SRX_CONV_1X1_MIN_PIXELS", 100000);
     k.strip_d2s = env_int("SRX_STRIP_D2S", 1);                 // 0: ESPCN's f3 on wide images stays off the pipelined strip kernel (A/B)
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
@@ -334,6 +336,11 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     if (g_use_pipe && knobs().kwrows_min_pixels >= 0 &&
         (launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err) ||                                      // (RGB-input 9x9 / 5x5: conv_pack3.hip)
          launch_conv_pack3(k, a, k.kh == 9 ? knobs().kwrows_min_pixels : knobs().big_route_min_pixels, s, &err))) {
+        if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
+        return SRX_OK;
+    }
+    // 1x1 layers on large inputs: HBM-bound, no LDS -- conv_1x1.hip (bit-identical to the kernels below)
+    if (g_use_pipe && knobs().conv_1x1_min_pixels >= 0 && launch_conv_1x1(k, a, knobs().conv_1x1_min_pixels, s, &err)) {
         if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
         return SRX_OK;
     }

@@ -766,3 +766,43 @@ def test_debug_poison_lds_entry_point(ops):
         assert _lib.lib().srx_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
         y = ops.conv2d_fwd(dev(x), dev(w), dev(b), 'same', 'relu')
         close(y, ref)
+
+
+@pytest.mark.parametrize('shape', [(1, 350, 300, 64, 32, 'relu'), (2, 231, 231, 64, 32, 'relu'), (1, 333, 307, 32, 64, None), (3, 200, 171, 64, 64, 'relu'),
+                                   (1, 317, 321, 32, 32, None)],
+                         ids=['1x350x300_64-32_relu', '2x231x231_64-32_relu', '1x333x307_32-64', '3x200x171_64-64_relu', '1x317x321_32-32'])
+def test_conv_1x1_streaming_route_forward_and_data_gradient(shape, ops):
+    """1x1 layers of 32 / 64 channels on inputs of at least 100,000 pixels (SRCNN's non-linear mapping layer, srcnn/srcnn.py:111-119,
+    on whole images and in its train step) run conv_1x1_kernel: pixels straight from global memory into MFMA operand layout, the
+    filter stationary, no LDS.  Forward (bias + none / ReLU) and the data gradient with the ReLU gradient of the layer input,
+    pixel counts that are not multiples of the 16-pixel step, several images: against the oracle, and equal to conv path 0
+    (conv_mfma_kernel: same products, same order)."""
+    N, H, W, Cin, Cout, act = shape
+    assert N * H * W >= 100000
+    rng = np.random.default_rng(zlib.crc32(repr(('c1x1',) + shape).encode()))
+    x = rng.uniform(-1, 1, (N, H, W, Cin)).astype(np.float32)
+    x *= (rng.uniform(size=x.shape) > 0.3)                 # (a post-ReLU input: zeros, whose gradient mask is 0)
+    x = np.abs(x).astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(Cin), (1, 1, Cin, Cout)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (Cout,)).astype(np.float32)
+    dpre = rng.normal(size=(N, H, W, Cout)).astype(np.float32)
+    xd, wd, bd, dd = dev(x), dev(w), dev(b), dev(dpre)
+    from ml_super_resolution_amd import _lib
+
+    def run():
+        y = ops.conv2d_fwd(xd, wd, bd, 'same', act)
+        dx = ops.conv2d_bwd_data(dd, wd, xd.shape, 'same', x_in=xd, in_act='relu')
+        dx_plain = ops.conv2d_bwd_data(dd, wd, xd.shape, 'same')
+        return y, dx, dx_plain
+    y, dx, dxp = run()
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        y0, dx0, dxp0 = run()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    close(y, O.c_conv2d_fwd(x, w, b, 'SAME', act))
+    ref = O.c_conv2d_bwd_data(dpre, w, (H, W), 'SAME')
+    close(dxp, ref)
+    close(dx, ref * (x > 0))
+    assert torch.equal(y, y0) and torch.equal(dx, dx0) and torch.equal(dxp, dxp0)
+    assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, 'same', act))

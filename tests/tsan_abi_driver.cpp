@@ -21,6 +21,7 @@ STUB_WGRAD(launch_wgrad) STUB_WGRAD(launch_wgrad_lin) STUB_WGRAD(launch_wgrad_li
 bool launch_wgrad_narrow(const ConvKey&, const WgradArgs&, int, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_narrow(const ConvKey&, const ConvArgs&, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_rows3x3(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
+bool launch_conv_1x1(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_pack3(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 bool launch_conv_kwrows(const ConvKey&, const ConvArgs&, long, hipStream_t, hipError_t* err) { *err = hipSuccess; return false; }
 hipError_t launch_reduce_partials(const float*, int, int, int, int, float*, float*, const float*, float, hipStream_t) { return hipSuccess; }
