@@ -1105,9 +1105,45 @@ __global__ __launch_bounds__(256) void rownorm_grad_kernel(const float* __restri
     }
 }
 
+// Long rows (SRCNN's crops: 231 x 231 = 53,361 elements per row, 192 rows per batch): one block per row is 192 blocks streaming
+// 427 KB each -- latency-bound (92 us for 82 MB).  Rows are cut into chunks of 4,096 elements, one block per chunk writes its
+// sum of squares, a second launch adds a row's chunks in order and takes the root.  The partial sums live in the first floats of
+// `dpred` (written before the gradient pass overwrites it): no extra workspace in the C ABI.
+constexpr int kRowChunk = 4096;
+__global__ __launch_bounds__(256) void rownorm_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              size_t row_len, int chunks, float* __restrict__ parts) {
+    __shared__ float sh[4];
+    const size_t row = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const size_t i0 = (size_t)chunk * kRowChunk, i1 = (i0 + kRowChunk < row_len) ? i0 + kRowChunk : row_len;
+    const float* pa = a + row * row_len;
+    const float* pb = b + row * row_len;
+    float acc = 0.f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float d = pa[i] - pb[i];
+        acc += d * d;
+    }
+    const float t = block_sum(acc, sh);
+    if (threadIdx.x == 0) parts[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void rownorm_finish_kernel(const float* __restrict__ parts, int chunks, size_t rows,
+                                                             float* __restrict__ norms) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += parts[row * chunks + c];
+    norms[row] = sqrtf(t);
+}
+
 hipError_t launch_rownorm_loss(const float* pred, const float* target, size_t rows, size_t row_len, float* loss,
                                float* dpred, float* norms, hipStream_t s) {
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)rows), dim3(256), 0, s, pred, target, row_len, norms);
+    const size_t chunks = (row_len + kRowChunk - 1) / kRowChunk;
+    if (dpred && chunks > 1 && rows * chunks < (1u << 30) && rows * chunks <= rows * row_len) {
+        hipLaunchKernelGGL(rownorm_partial_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, s, pred, target, row_len, (int)chunks, dpred);
+        hipLaunchKernelGGL(rownorm_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, dpred, (int)chunks, rows, norms);
+    } else {
+        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)rows), dim3(256), 0, s, pred, target, row_len, norms);
+    }
     if (loss) hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, norms, (int)rows, 1.0f / (float)rows, loss, 0);
     if (dpred)
         hipLaunchKernelGGL(rownorm_grad_kernel, dim3(ew_grid(rows * row_len, 1)), dim3(256), 0, s, pred, target, rows,

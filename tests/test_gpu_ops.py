@@ -806,3 +806,28 @@ def test_conv_1x1_streaming_route_forward_and_data_gradient(shape, ops):
     close(dx, ref * (x > 0))
     assert torch.equal(y, y0) and torch.equal(dx, dx0) and torch.equal(dxp, dxp0)
     assert torch.equal(y, ops.conv2d_fwd(xd, wd, bd, 'same', act))
+
+
+@pytest.mark.parametrize('shape', [(4, 231, 231, 3), (2, 71, 71, 3), (3, 64, 64, 1), (5, 21, 21, 3)],
+                         ids=['srcnn_crop_231', 'row_of_5041_two_chunks', 'row_of_4096_exactly', 'short_rows_one_block_each'])
+def test_rownorm_loss_on_long_rows(shape, ops):
+    """SRCNN's loss (srcnn/srcnn.py:142-144: mean over rows of ||reshape(sr - hi, [-1, bb^2])||_2) and its gradient on rows longer
+    than one 4,096-element chunk -- the reference's 231 x 231 crops are rows of 53,361 -- where the sum of squares of a row is
+    taken by one block per chunk and finished in a second launch (partial sums parked in the gradient buffer); rows of exactly
+    one chunk and short rows take the one-block-per-row kernel.  Against the float64 oracle; deterministic; loss only (no
+    gradient buffer) gives the same loss to rounding."""
+    rng = np.random.default_rng(zlib.crc32(repr(('rownorm',) + shape).encode()))
+    sr = rng.uniform(-1, 1, shape).astype(np.float32)
+    hi = rng.uniform(-1, 1, shape).astype(np.float32)
+    ref_loss, ref_grad = O.srcnn_loss_and_grad(sr, hi)
+    loss = torch.zeros((), device='cuda')
+    row_len = shape[1] * shape[2]
+    d = ops.rownorm_loss_fwd_bwd(dev(sr), dev(hi), row_len, loss)
+    assert abs(float(loss) - ref_loss) <= 2e-6 * ref_loss
+    close(d, ref_grad)
+    loss2 = torch.zeros((), device='cuda')
+    d2 = ops.rownorm_loss_fwd_bwd(dev(sr), dev(hi), row_len, loss2)
+    assert torch.equal(d, d2) and float(loss) == float(loss2)
+    loss3 = torch.zeros((), device='cuda')
+    ops.rownorm_loss_fwd_bwd(dev(sr), dev(hi), row_len, loss3, want_grad=False)
+    assert abs(float(loss3) - ref_loss) <= 2e-6 * ref_loss
