@@ -6,7 +6,7 @@ sub-pixel map on shapes whose chunks end within 6 float4 of a multiple of 256 (t
 device-state Adam against the host-argument one.
 Late in the round: the RGB-input packed-K kernel (oracle + bit-identity with conv path 0), the two-chunk pipelined strips (tanh epilogue;
 sub-pixel epilogue), the one-launch ESPCN kernel with tiles up to 16 x 16, the exact-rows filter gradient on 41-pixel rows.
-Usage: fuzz_round4.py [cases] [seed] [wgrad_strip|kwrows|subpixel|adam|pack3|strip2|espcn_one_launch|wgrad_rows41]"""
+Usage: fuzz_round4.py [cases] [seed] [wgrad_strip|kwrows|subpixel|adam|pack3|strip2|espcn_one_launch|wgrad_rows41|conv1x1]"""
 import os, sys
 import numpy as np
 import torch
@@ -183,6 +183,29 @@ def case_espcn_one_launch(rng):
     return ok, 'espcn one launch r%d %dx%dx%d' % (r, n, h, w)
 
 
+def case_conv1x1(rng):
+    # streaming 1x1 forward / data gradient (from 100,000 pixels): oracle parity and equality with conv path 0
+    cin, cout = [(64, 32), (32, 64), (64, 64), (32, 32)][rng.integers(4)]
+    act = [None, 'relu'][rng.integers(2)]
+    n = int(rng.integers(1, 5))
+    h, w = int(rng.integers(40, 400)), int(rng.integers(40, 400))
+    while n * h * w < 100000:
+        h += 31; w += 17
+    if n * h * w > 400000:
+        n = 1
+    x = np.abs(rng.uniform(-1, 1, (n, h, w, cin))).astype(np.float32) * (rng.uniform(size=(n, h, w, cin)) > 0.3)
+    x = x.astype(np.float32)
+    wt = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+    dpre = rng.normal(size=(n, h, w, cout)).astype(np.float32)
+    xd, wd, bd, dd = dev(x), dev(wt), dev(b), dev(dpre)
+    run = lambda: (ops.conv2d_fwd(xd, wd, bd, 'same', act), ops.conv2d_bwd_data(dd, wd, xd.shape, 'same', x_in=xd, in_act='relu'))
+    y, dx = run()
+    y0, dx0 = _path0(run)
+    ok = close(y, O.c_conv2d_fwd(x, wt, b, 'SAME', act)) and close(dx, O.c_conv2d_bwd_data(dpre, wt, (h, w), 'SAME') * (x > 0))
+    return ok and torch.equal(y, y0) and torch.equal(dx, dx0), 'conv1x1 %d->%d %s %dx%dx%d' % (cin, cout, act, n, h, w)
+
+
 def case_wgrad_rows41(rng):
     n = int(rng.integers(1, 40))
     h = 41 if rng.random() < 0.5 else int(rng.integers(1, 90))
@@ -197,7 +220,7 @@ def case_wgrad_rows41(rng):
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    kinds = [case_wgrad_strip, case_kwrows, case_subpixel, case_adam, case_pack3, case_strip2, case_espcn_one_launch, case_wgrad_rows41]
+    kinds = [case_wgrad_strip, case_kwrows, case_subpixel, case_adam, case_pack3, case_strip2, case_espcn_one_launch, case_wgrad_rows41, case_conv1x1]
     if len(sys.argv) > 3:
         kinds = [k for k in kinds if k.__name__ == 'case_' + sys.argv[3]]
     nbad = 0
