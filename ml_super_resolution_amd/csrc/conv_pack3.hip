@@ -12,6 +12,9 @@
 // window) would reach this output too; images are finite (uint8-derived), conv path 0 has no such slot.  Thresholds
 // (srx_api.hip): 9x9 from 4,096 output pixels, 5x5 from 60,000 (smaller ESPCN inputs take the one-launch kernel).
 //
+// (End of round 4: the same kernel as the DATA GRADIENT of SRCNN's 5x5 32 -> 3 layer -- a 5x5 "forward" from the 3 channels of dpre
+// to 32 channels with the filter flipped and transposed and the ReLU gradient of the layer input as epilogue: template WT.)
+//
 // One workgroup of 8 waves per CU; a tile is 32 output rows x 64 output columns (its input halo: <= 40 x 72 pixels = 34.6 KB);
 // wave = (16-channel chunk, row parity): it walks its rows, four 16-pixel sub-tiles (= the strip's 64 columns) at a time,
 // MFMAs pinned in blocks of 4 (one per sub-tile, one weight register) with the LDS reads of the next block issued first;
@@ -29,7 +32,11 @@ __device__ __forceinline__ void mfma4_shared_a(f32x4 (&c)[4], float w, float b0,
                  : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "v"(w), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
-template <int KH, int KW>
+// COUT = 64: 4 channel chunks x 2 row phases; COUT = 32: 2 chunks x 4 row phases.
+// WT: the DATA GRADIENT of a k x k layer with 3 output channels (SRCNN's reconstruction layer, srcnn/srcnn.py:122-130): x is dpre
+// [N,H,W,3], w the forward layer's HWIO array [KH,KW,COUT,3] read flipped and transposed, no bias, the ReLU gradient of the
+// layer input (a.mask) as the epilogue.
+template <int KH, int KW, int COUT = 64, bool WT = false>
 __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs a, int units_total) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KR = 3 * KW;                  // (kw, ci) values of one filter row
@@ -40,7 +47,8 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    const int chunk = wave & 3, par = wave >> 2;
+    constexpr int NCHK = COUT / 16, PH = kNW / NCHK;
+    const int chunk = wave % NCHK, par = wave / NCHK;
     const int co = 16 * chunk + li;             // A operand: the lane's output channel
 
     // stationary weights: wr[kh][j] = w[kh][k / 3][k % 3][co], k = 4 j + kq (zero past the filter row)
@@ -51,7 +59,9 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
         for (int j = 0; j < NJ; ++j) {
             const int kk = 4 * j + kq;
             const bool ok = kk < KR && co < a.Cout;
-            const float v = a.w[ok ? ((size_t)(kh * KW) * 3 + kk) * a.Cout + co : 0];      // ((kh KW + kw) 3 + ci) = kh KW 3 + k
+            size_t wi = ((size_t)(kh * KW) * 3 + kk) * a.Cout + co;                         // ((kh KW + kw) 3 + ci) = kh KW 3 + k
+            if (WT) wi = ((size_t)((KH - 1 - kh) * KW + (KW - 1 - kk / 3)) * a.Cout + co) * 3 + kk % 3;   // w_f[KH-1-kh][KW-1-kw][co][c]
+            const float v = a.w[ok ? wi : 0];
             wr[kh * NJ + j] = ok ? v : 0.0f;
         }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -94,10 +104,20 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
         }
         lds_barrier();
         float* yn = a.y + ((size_t)n * a.OH + h0) * a.OW * a.Cout;
-        for (int r = par; r < th; r += 2) {
+        const float* mn = (WT && a.mask) ? a.mask + ((size_t)n * a.OH + h0) * a.OW * a.Cout : nullptr;
+        for (int r = par; r < th; r += PH) {
             // B operand of sub-tile g (columns 16 g + li), block (kh, j): float ((r + kh) RSW + 16 g + li) 3 + 4 j + kq
             const float* px = lds + (r * RSW + li) * 3 + kq;
             f32x4 acc[4] = {bias4, bias4, bias4, bias4};
+            // (data gradient: the row's mask values are requested here and used after the MFMA blocks)
+            f32x4 mrow[WT ? 4 : 1];
+            if (WT && mn && cb < a.Cout) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool in = 16 * g + li < tw;
+                    mrow[g] = in ? *reinterpret_cast<const f32x4*>(mn + ((size_t)r * a.OW + ow0 + li + 16 * g) * a.Cout + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
             float c0 = px[0], c1 = px[48], c2 = px[96], c3 = px[144];
 #pragma unroll
             for (int t = 0; t < NBLK; ++t) {
@@ -116,7 +136,19 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
                 float* yo = yn + ((size_t)r * a.OW + ow0 + li) * a.Cout + cb;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (16 * g + li < tw) *reinterpret_cast<f32x4*>(yo + (size_t)16 * g * a.Cout) = act_apply4(acc[g], a.act, slope);
+                    if (16 * g + li < tw) {
+                        f32x4 v = acc[g];
+                        if (WT) {
+                            if (mn) {
+                                const f32x4 m = mrow[WT ? g : 0];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.0f;
+                            }
+                        } else {
+                            v = act_apply4(v, a.act, slope);
+                        }
+                        *reinterpret_cast<f32x4*>(yo + (size_t)16 * g * a.Cout) = v;
+                    }
             }
         }
         u += th;
@@ -127,8 +159,15 @@ __global__ __launch_bounds__(64 * kNW, 1) void conv_pack3_kernel(const ConvArgs 
 
 // Returns true when this route took the launch.  min_pixels: below it the layer stays on conv_mfma_kernel.
 bool launch_conv_pack3(const ConvKey& k, const ConvArgs& a, long min_pixels, hipStream_t s, hipError_t* err) {
-    if (k.wt || a.skip || a.mask || a.d2s_r || a.stride != 1 || a.post_relu) return false;
-    if (a.Cin != 3 || a.Cout != 64 || !((k.kh == 9 && k.kw == 9) || (k.kh == 5 && k.kw == 5))) return false;
+    if (a.skip || a.d2s_r || a.stride != 1 || a.post_relu) return false;
+    if (k.wt) {
+        // data gradient of a 5x5 layer with 3 output channels and 32 input channels (dx: 32 channels), ReLU mask or none
+        if (a.Cin != 3 || a.Cout != 32 || k.kh != 5 || k.kw != 5 || a.bias || a.act != ACT_NONE || (a.mask && a.mask_act != ACT_RELU)) return false;
+        if (((uintptr_t)a.y | (uintptr_t)(a.mask ? a.mask : a.y)) & 15u) return false;
+    } else {
+        if (a.mask) return false;
+        if (a.Cin != 3 || a.Cout != 64 || !((k.kh == 9 && k.kw == 9) || (k.kh == 5 && k.kw == 5))) return false;
+    }
     if ((long)a.N * a.OH * a.OW < min_pixels) return false;
     if ((long)a.H * a.W * 3 * 4 >= (1L << 31) - 4096) return false;
     ConvArgs b = a;
@@ -141,11 +180,13 @@ bool launch_conv_pack3(const ConvKey& k, const ConvArgs& a, long min_pixels, hip
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else (void)hipGetLastError();
     }
-    // every CU gets a range of strip rows (at least two: the two row parities of the waves); a tile is up to kTH of them
-    const long ranges = (units + 1) / 2;
+    // every CU gets a range of strip rows (at least one per row phase of the waves); a tile is up to kTH of them
+    const int phases = kNW / (a.Cout / 16);                     // row phases of the waves: 2 (64 channels) or 4 (32)
+    const long ranges = (units + phases - 1) / phases;
     const int grid = (int)(ranges < cus ? ranges : cus);
     const size_t lds = (size_t)(kTH + k.kh - 1) * (kTW + k.kw - 1) * 3 * sizeof(float) + 16;     // (+ the zero-weighted slots past the last pixel)
-    if (k.kh == 9) hipLaunchKernelGGL((conv_pack3_kernel<9, 9>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
+    if (k.wt) hipLaunchKernelGGL((conv_pack3_kernel<5, 5, 32, true>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
+    else if (k.kh == 9) hipLaunchKernelGGL((conv_pack3_kernel<9, 9>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
     else hipLaunchKernelGGL((conv_pack3_kernel<5, 5>), dim3(grid), dim3(64 * kNW), lds, s, b, (int)units);
     *err = hipGetLastError();
     return true;

@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // Tuning / A-B knobs from the environment, read ONCE (C++11 function-local statics are initialised thread-safely):
 // the ABI promises concurrent calls from several host threads on different streams.
 struct Knobs {
-    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels, strip_d2s, conv_1x1_min_pixels;
+    int pipe_default, min_full_th, small_rule, th, grid, narrow, dyn, stagger, wgrad_lin, wgrad_pipe, wgrad_pipe_strip, wgrad_rows_full, wgrad_1x1, wgrad_pack3, wgrad_nt, kwrows_min_pixels, big_route_min_pixels, strip_d2s, conv_1x1_min_pixels, pack3_dgrad;
     int subpixel_chunk_kb, subpixel_db, subpixel_grid, subpixel_depth, subpixel_throttle, subpixel_even;
     unsigned long long* trace;
     int dbg;
@@ -49,6 +49,7 @@ Knobs read_knobs() {
     k.big_route_min_pixels = env_int("SRX_BIG_ROUTE_MIN_PIXELS", 60000);
     // 1x1 forward / data gradient (32 / 64 channels) on the streaming conv_1x1_kernel from this many pixels (negative: never)
     k.conv_1x1_min_pixels = env_int("SRX_CONV_1X1_MIN_PIXELS", 100000);
+    k.pack3_dgrad = env_int("SRX_PACK3_DGRAD", 1);             // 0: the 5x5 32->3 layer's data gradient stays on conv_mfma_kernel (A/B)
     k.strip_d2s = env_int("SRX_STRIP_D2S", 1);                 // 0: ESPCN's f3 on wide images stays off the pipelined strip kernel (A/B)
     k.wgrad_rows_full = env_int("SRX_WGRAD_ROWS_FULL", 1);     // 0: 41-pixel rows on the padded-position walk (wgrad_pipe_kernel) instead of wgrad_rows_full_kernel (A/B)
     k.wgrad_1x1 = env_int("SRX_WGRAD_1X1", 1);                 // 0: 1x1 filter gradients on wgrad_mfma_kernel instead of the streaming wgrad_1x1_kernel (A/B)
@@ -335,7 +336,8 @@ int dispatch_conv(const Plan& p_in, bool wt, const ConvArgs& a_in, hipStream_t s
     // (srx_set_conv_path(0) keeps every shape on the conv_mfma_kernel family: the reference point of the bit-identity tests.)
     if (g_use_pipe && knobs().kwrows_min_pixels >= 0 &&
         (launch_conv_kwrows(k, a, knobs().kwrows_min_pixels, s, &err) ||                                      // (RGB-input 9x9 / 5x5: conv_pack3.hip)
-         launch_conv_pack3(k, a, k.kh == 9 ? knobs().kwrows_min_pixels : knobs().big_route_min_pixels, s, &err))) {
+         ((!k.wt || knobs().pack3_dgrad) &&
+          launch_conv_pack3(k, a, k.kh == 9 ? knobs().kwrows_min_pixels : knobs().big_route_min_pixels, s, &err)))) {
         if (err != hipSuccess) return fail(SRX_ERR_LAUNCH, "conv launch failed: %s", hipGetErrorString(err));
         return SRX_OK;
     }

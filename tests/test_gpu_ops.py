@@ -831,3 +831,37 @@ def test_rownorm_loss_on_long_rows(shape, ops):
     loss3 = torch.zeros((), device='cuda')
     ops.rownorm_loss_fwd_bwd(dev(sr), dev(hi), row_len, loss3, want_grad=False)
     assert abs(float(loss3) - ref_loss) <= 2e-6 * ref_loss
+
+
+@pytest.mark.parametrize('shape', [(2, 231, 231, 'VALID'), (1, 300, 250, 'SAME'), (5, 120, 131, 'VALID'), (1, 263, 241, 'VALID')],
+                         ids=['2x231x231_valid', '1x300x250_same', '5x120x131_valid', '1x263x241_valid'])
+def test_data_gradient_of_5x5_32_to_3_on_the_packed_k_kernel(shape, ops):
+    """The data gradient of SRCNN's reconstruction layer (srcnn/srcnn.py:122-130: 5x5 32 -> 3; dx has 32 channels) on inputs of at
+    least 60,000 pixels runs conv_pack3_kernel<5,5,32,WT>: dpre's 3 channels as 3-float LDS pixels with (kw, co) along the MFMA's
+    K, the filter flipped and transposed, the ReLU gradient of the layer input as epilogue.  VALID (the reference's geometry:
+    the gradient image is 4 pixels larger than dpre on every side... of zeros) and SAME; with and without the mask; against the
+    oracle and equal to conv path 0."""
+    N, H, W, pad = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('dgrad5',) + shape).encode()))
+    x = np.abs(rng.uniform(-1, 1, (N, H, W, 32))).astype(np.float32) * (rng.uniform(size=(N, H, W, 32)) > 0.3)
+    x = x.astype(np.float32)
+    w = rng.normal(0, 1.0 / np.sqrt(75), (5, 5, 32, 3)).astype(np.float32)
+    oh, ow = (H, W) if pad == 'SAME' else (H - 4, W - 4)
+    dpre = rng.normal(size=(N, oh, ow, 3)).astype(np.float32)
+    assert N * H * W >= 60000
+    xd, wd, dd = dev(x), dev(w), dev(dpre)
+    from ml_super_resolution_amd import _lib
+
+    def run():
+        return (ops.conv2d_bwd_data(dd, wd, xd.shape, pad.lower(), x_in=xd, in_act='relu'), ops.conv2d_bwd_data(dd, wd, xd.shape, pad.lower()))
+    dx, dxp = run()
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        dx0, dxp0 = run()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    ref = O.c_conv2d_bwd_data(dpre, w, (H, W), pad)
+    close(dxp, ref)
+    close(dx, ref * (x > 0))
+    assert torch.equal(dx, dx0) and torch.equal(dxp, dxp0)
+    assert torch.equal(dx, run()[0])
