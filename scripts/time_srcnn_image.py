@@ -18,7 +18,9 @@ def timed(fn, it=30):
     for _ in range(it): fn()
     e.record(); e.synchronize()
     return s.elapsed_time(e) / it * 1e3
-for n, h, w in ((1, 512, 512), (1, 720, 1280), (16, 128, 128), (64, 33, 33)):
+args = [int(v) for v in sys.argv[1:]]
+shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(1, 512, 512), (1, 720, 1280), (16, 128, 128), (64, 33, 33)]
+for n, h, w in shapes:
     x = rnd(n, h, w, 3)
     t1 = ops.conv2d_fwd(x, w1, b1, 'valid', 'relu')
     t2 = ops.conv2d_fwd(t1, w2, b2, 'valid', 'relu')
