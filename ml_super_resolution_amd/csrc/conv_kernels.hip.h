@@ -97,6 +97,34 @@ __device__ __forceinline__ float srx_tanhf(float x) {
     return copysignf(ax < 0.55f ? small : big, x);
 }
 
+// The same function on two values at once: every multiply / add / fma below is ONE packed instruction for the pair
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32; gfx90a+), 23 VALU instructions per pair instead of 2 x 16 -- the VALU work of an
+// epilogue adds to the fp32 MFMA time, so the count is what matters.  Same operations in the same order as
+// srx_tanhf: the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 srx_tanhf2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 x2 = ax * ax;
+    f32x2 p = __builtin_elementwise_fma(x2, f32x2{-0.006274174898862839f, -0.006274174898862839f}, f32x2{0.021071631461381912f, 0.021071631461381912f});
+    p = __builtin_elementwise_fma(x2, p, f32x2{-0.053852297365665436f, -0.053852297365665436f});
+    p = __builtin_elementwise_fma(x2, p, f32x2{0.13332585990428925f, 0.13332585990428925f});
+    p = __builtin_elementwise_fma(x2, p, f32x2{-0.33333316445350647f, -0.33333316445350647f});
+    const f32x2 small = __builtin_elementwise_fma(x2 * ax, p, ax);
+    const f32x2 t = ax * 2.8853900817779268f;
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    const f32x2 big = __builtin_elementwise_fma(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
+    f32x2 o;
+    o[0] = copysignf(ax[0] < 0.55f ? small[0] : big[0], x[0]);
+    o[1] = copysignf(ax[1] < 0.55f ? small[1] : big[1], x[1]);
+    return o;
+}
+__device__ __forceinline__ f32x4 srx_tanhf4(f32x4 v) {
+    const f32x2 a = srx_tanhf2(f32x2{v[0], v[1]}), b = srx_tanhf2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.0f);
@@ -241,8 +269,9 @@ __device__ __forceinline__ float act_slope(int act) {
 // registers around every call -- swapping libdevice's tanhf for srx_tanhf inside the out-of-line function changed nothing
 // (ESPCN f1 at 720 x 1280: 133 -> 135 us); inlining it did.)
 __device__ __forceinline__ f32x4 act_transcendental4(f32x4 v, int act) {
+    if (act == ACT_TANH) return srx_tanhf4(v);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (act == ACT_TANH) ? srx_tanhf(v[e]) : 1.0f / (1.0f + __expf(-v[e]));
+    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
     return v;
 }
 
@@ -1009,8 +1038,7 @@ template <int MAXG, int AUX, int NPART, bool Z = false>
 __device__ __forceinline__ void pipe_epilogue_one(const PipePend<MAXG, AUX>& pd, int i, const PipeEpi& ep, int vst) {
     f32x4 v = pd.acc[i];
     if (AUX == 3) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float f = v[e]; v[e] = srx_tanhf(f); }
+        v = srx_tanhf4(v);
     } else if (AUX == 1) {
         const f32x4 m = pd.aux[AUX ? i : 0];
 #pragma unroll

@@ -43,11 +43,7 @@ constexpr int kT2 = (kT + 2) * (kT + 2) * kP2;
 constexpr int kShared = kT2 > kX0 ? kT2 : kX0;
 static_assert((size_t)(kT1 + kShared) * 4 <= 160 * 1024, "tile does not fit the LDS");
 
-__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = srx_tanhf(v[e]);
-    return v;
-}
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) { return srx_tanhf4(v); }
 
 // A wave's sub-tiles of a phase are m = first, first + step, ... (count of them); they are processed in groups of G <= 4
 // accumulators, the groups evened out (9 sub-tiles: 3 + 3 + 3, not 4 + 4 + 1 with three idle accumulators' worth of
