@@ -268,7 +268,7 @@ def under_profiler():
         any(k.startswith(('ROCPROF', 'ROCPROFILER_')) for k in env)
 
 
-def live_traffic(timeout_s=240):
+def live_traffic(timeout_s=120):
     """`roofline.traffic` measured IN THIS RUN: two child processes `rocprofv3 --kernel-trace --pmc <counter> -- python3
     scripts/prof_conv.py 10 fwd` (FETCH_SIZE and WRITE_SIZE need a pass each; nothing but --kernel-trace beside --pmc),
     started BEFORE this process touches the GPU (a process that has initialised the GPU must not start programs).
