@@ -458,14 +458,16 @@ def extras(model, dev, stream, x64, y64, px):
         em = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0), device=dev, seed=1)
         sdb, bqb, hdb = next(enet_train.synthetic_batches(nb, dev))
         em.g_step(sdb, bqb, hdb); em.d_step(sdb, bqb, hdb)
-        g_ms = hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream)
-        d_ms = hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream)
+        # (≈ 380 launches per cycle issued from Python: on a host loaded by other tenants the launch thread falls behind the
+        # GPU -- 36-39 ms seen against 31.3 -- so the faster of two short loops is reported)
+        g_ms = min(hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream) for _ in range(2))
+        d_ms = min(hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream) for _ in range(2))
         flop = 3 * 12.78e9 * nb + 3 * 2 * 110380.0 * 128 * 128 * nb + 2 * 2 * 0.468e9 * nb
         out['enet_pat'] = {'batch': nb, 'patch': '32->128', 'g_trainer_ms': round(g_ms, 2), 'd_trainer_ms': round(d_ms, 2),
                            'patches_per_s': round(3 * nb / ((d_ms + 3 * g_ms) * 1e-3), 1),
                            'g_trainer_tflops': round(flop / (g_ms * 1e-3) / 1e12, 1),
                            'g_trainer_frac_of_fp32_mfma_peak': round(flop / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
-                           'weights': 'random VGG-shaped (timing only)'}
+                           'weights': 'random VGG-shaped (timing only)', 'statistic': 'faster of two loops of 3 runs'}
         del em, sdb, bqb, hdb
         # the tile shape BASELINE's config names: 512x512 HR tiles, 4 per GPU (the discriminator's first dense layer
         # grows to 16*16*512 inputs)
@@ -474,8 +476,8 @@ def extras(model, dev, stream, x64, y64, px):
             em = model_enet.EnetModel('pat', model_vgg.random_vgg_weights(0), device=dev, seed=1, image_size=512)
             sdb, bqb, hdb = next(enet_train.synthetic_batches(nt, dev, hd_size=512))
             em.g_step(sdb, bqb, hdb); em.d_step(sdb, bqb, hdb)
-            g_ms = hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream)
-            d_ms = hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream)
+            g_ms = min(hip_event_time_ms(lambda: em.g_step(sdb, bqb, hdb), 3, stream) for _ in range(2))
+            d_ms = min(hip_event_time_ms(lambda: em.d_step(sdb, bqb, hdb), 3, stream) for _ in range(2))
             out['enet_pat']['tiles_512'] = {'batch': nt, 'patch': '128->512', 'g_trainer_ms': round(g_ms, 2), 'd_trainer_ms': round(d_ms, 2),
                                             'g_trainer_frac_of_fp32_mfma_peak': round(16 * nt / nb * flop / (g_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
             del em
