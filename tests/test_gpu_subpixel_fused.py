@@ -176,3 +176,54 @@ def test_srcnn_single_launch_equals_three_launches(n, h, w):
         assert torch.equal(dflt, three)
     with pytest.raises(ValueError):
         ops.srcnn_forward(x[:, :12], [(m.stack.kernel(i), m.stack.bias(i)) for i in range(3)])
+
+
+def test_espcn_720p_routes_equal_conv_path_0():
+    """ESPCN 3x on one 720 x 1280 LR frame -- the size the whole-image numbers of DESIGN.md are quoted at: f1 on conv_pack3_kernel,
+    f2 on the two-chunk pipelined strips with the tanh epilogue (40 strips x 720 rows), f3 on the same strips with the sub-pixel
+    map as epilogue.  Too large for the oracle in a test; the size-independent property: every route is bit-identical to conv
+    path 0 (conv_mfma_kernel for all three layers, itself checked against the oracle on smaller shapes), and deterministic."""
+    from ml_super_resolution_amd import _lib
+    from ml_super_resolution_amd.espcn import model_espcn
+    m = model_espcn.EspcnModel(3, device='cuda', seed=9)
+    for i in range(3):
+        m.stack.bias(i).copy_(torch.linspace(-0.1, 0.1, m.stack.bias(i).numel(), device='cuda'))
+    g = torch.Generator(device='cuda').manual_seed(720)
+    x = torch.rand((1, 720, 1280, 3), device='cuda', generator=g) * 2 - 1
+    hr = m.super_resolve(x, use_graph=False, single_launch=False).clone()
+    assert hr.shape == (1, 2160, 3840, 3) and torch.isfinite(hr).all()
+    assert torch.equal(m.super_resolve(x, use_graph=True, single_launch=False), hr)
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        hr0 = m.super_resolve(x, use_graph=False, single_launch=False).clone()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert torch.equal(hr, hr0)
+    assert float(hr.abs().max()) > 1e-3
+
+
+def test_srcnn_720p_routes_against_conv_path_0():
+    """SRCNN 9-1-5 on one 720 x 1280 frame (the size of DESIGN.md's whole-image numbers): conv_pack3_kernel<9,9> and conv_1x1_kernel
+    are bit-identical to conv path 0 layer by layer; conv_kwrows_kernel agrees with it to rounding (another order of the kw
+    partial sums); the whole net therefore to <= 2e-6 of its scale."""
+    from ml_super_resolution_amd import _lib, ops
+    g = torch.Generator(device='cuda').manual_seed(1280)
+    rnd = lambda *s, sc=1.0: (torch.rand(s, device='cuda', generator=g) * 2 - 1) * sc
+    w1, b1 = rnd(9, 9, 3, 64, sc=0.06), rnd(64, sc=0.1)
+    w2, b2 = rnd(1, 1, 64, 32, sc=0.12), rnd(32, sc=0.1)
+    w3, b3 = rnd(5, 5, 32, 3, sc=0.03), rnd(3, sc=0.1)
+    x = rnd(1, 720, 1280, 3)
+
+    def layers():
+        t1 = ops.conv2d_fwd(x, w1, b1, 'valid', 'relu')
+        t2 = ops.conv2d_fwd(t1, w2, b2, 'valid', 'relu')
+        return t1, t2, ops.conv2d_fwd(t2, w3, b3, 'valid', 'tanh')
+    t1, t2, y = layers()
+    old = _lib.lib().srx_set_conv_path(0)
+    try:
+        t1_0, t2_0, y_0 = layers()
+    finally:
+        _lib.lib().srx_set_conv_path(old)
+    assert y.shape == (1, 708, 1268, 3) and torch.isfinite(y).all()
+    assert torch.equal(t1, t1_0) and torch.equal(t2, t2_0)
+    assert float((y - y_0).abs().max()) <= 2e-6 * max(1.0, float(y_0.abs().max())) and not torch.equal(y, y_0)
